@@ -1,0 +1,58 @@
+"""ctypes binding of libibloc_hip.so (the C-ABI declared in include/ibloc.h).
+
+The HIP library is the product path: if it is missing or fails to load this module raises --
+there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libibloc_hip.so")
+
+
+class IblError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise IblError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C instance-based-loc_amd/csrc`). There is no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+c_i32p = C.POINTER(C.c_int32)
+c_u16p = C.POINTER(C.c_uint16)
+vp = C.c_void_p
+
+_SIGS = {
+    "ibl_version": (C.c_int, []),
+    "ibl_last_error": (C.c_char_p, []),
+    "ibl_normalize_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+    "ibl_closest_similarity_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "ibl_closest_similarity": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, vp, vp, vp,
+                                         C.c_int64, vp]),
+    "ibl_assign_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int]),
+}
+
+
+def _bind():
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+
+
+_bind()
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib.ibl_last_error()
+        raise IblError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+def declared_symbols():
+    return list(_SIGS.keys())

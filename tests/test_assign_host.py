@@ -1,0 +1,78 @@
+"""ibl_assign_batch (host C++ inside libibloc_hip.so) vs the reference golden vectors and the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import simvolume_oracle as so
+from ibloc_amd.assign import assign_batch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "simvolume_golden.json")
+with open(GOLD) as f:
+    CASES = json.load(f)["cases"]
+
+
+def run(sims, npl=4):
+    aug = so._augment(np.asarray(sims, dtype=np.float32))
+    return assign_batch(aug[None], [aug.shape[0]], npl)[0]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_matches_reference_golden(case):
+    assert run(case["sims"], case["num_per_length"]) == case["expected"]
+
+
+def _rand_case(rng, Q, M, kind):
+    if kind == "uniform":
+        return rng.uniform(-1, 1, size=(Q, M))
+    if kind == "peaked":
+        s = rng.normal(0, 0.05, size=(Q, M))
+        for i in range(Q):
+            s[i, rng.integers(0, M)] = rng.uniform(0.5, 0.99)
+        return s
+    if kind == "ties":
+        return rng.choice([0.25, 0.5, -0.5, 0.125, 1.0, 0.0], size=(Q, M))
+    if kind == "coarse":
+        return np.round(rng.uniform(-1, 1, size=(Q, M)) * 8) / 8
+    if kind == "neg":
+        return -np.abs(rng.uniform(0.01, 1, size=(Q, M)))
+    if kind == "tinyvals":
+        return rng.uniform(-1, 1, size=(Q, M)) * 1e-3
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "peaked", "ties", "coarse", "neg", "tinyvals"])
+@pytest.mark.parametrize("Q,M", [(2, 200), (3, 33), (3, 40), (3, 64), (4, 36), (5, 34), (2, 181), (7, 33)])
+def test_pruned_search_matches_oracle(kind, Q, M):
+    # sizes beyond the brute-force threshold of csrc/assign.cpp so the pruned search + tie scan run
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{kind}-{Q}-{M}".encode()))
+    for _ in range(3):
+        sims = _rand_case(rng, Q, M, kind).astype(np.float32)
+        assert run(sims) == so.simvolume_assignments(sims, 4)
+
+
+def test_batch_with_ragged_q():
+    rng = np.random.default_rng(7)
+    M, Qs = 45, 7
+    qs = [1, 2, 3, 7, 5, 4]
+    aug = np.ones((len(qs), Qs, M + 1), dtype=np.float16)
+    exp = []
+    for f, q in enumerate(qs):
+        s = rng.uniform(-1, 1, size=(q, M)).astype(np.float32)
+        aug[f, :q, :-1] = s
+        exp.append(so.simvolume_assignments(s, 4))
+    got = assign_batch(aug, qs, 4, n_threads=3)
+    assert got == exp
+
+
+def test_simvolume_facade_matches_reference_main_case():
+    from ibloc_amd.utils.similarity_volume import SimVolume
+    cs = np.zeros((10, 4), dtype=np.float32)
+    for i in range(10):
+        for j in range(4):
+            cs[i, j] = i + j
+    sv = SimVolume(cs)
+    sv.fast_construct_volume(3)
+    assert sv.get_top_indices_from_subvolumes(3) == CASES[0]["expected"]
