@@ -29,9 +29,9 @@ __global__ __launch_bounds__(256) void ibl_normalize_rows_kernel(const float* __
     for (int i = lane; i < dim; i += 64) s = __builtin_fmaf(x[i], x[i], s);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
-    const float nrm = __fsqrt_rn(s);
+    const float nrm = __builtin_sqrtf(s);   // correctly rounded (default -fhip-fp32-correctly-rounded-divide-sqrt)
     float* y = out + row * dim;
-    for (int i = lane; i < dim; i += 64) y[i] = __fdiv_rn(x[i], nrm);
+    for (int i = lane; i < dim; i += 64) y[i] = x[i] / nrm;
 }
 
 extern "C" int ibl_normalize_rows(const float* in, float* out, int64_t n_rows, int dim, void* stream) {
