@@ -35,6 +35,86 @@ int ibl_version(void);
 const char* ibl_last_error(void);
 
 /* ------------------------------------------------------------------------------------------ */
+/* embed: crop preprocessing + ViT encoder forward                       */
+/* ------------------------------------------------------------------------------------------ */
+
+#define IBL_VIT_MAX_LAYERS 32
+#define IBL_VIT_LAYERSCALE 1      /* DINOv2 LayerScale (per-layer ls1/ls2 non-NULL)                */
+#define IBL_VIT_PRE_LN 2          /* CLIP ln_pre on the embedded tokens                            */
+#define IBL_VIT_FINAL_LN 4        /* final LayerNorm (DINOv2 / ViT layernorm, CLIP ln_post)        */
+#define IBL_VIT_QUICK_GELU 8      /* x*sigmoid(1.702x) (OpenAI CLIP); laion2b ViT-B-32 uses GELU   */
+#define IBL_VIT_PROJ 16           /* CLS -> out_dim projection (CLIP visual.proj)                  */
+#define IBL_VIT_OUT_ALL_TOKENS 32 /* return every token (DATOR/TransReID local_feature=True)       */
+
+typedef struct {
+    int32_t dim, depth, heads, mlp_dim;
+    int32_t patch, img_h, img_w;   /* model input size after preprocessing                          */
+    int32_t n_tokens;              /* 1 + (img_h/patch)*(img_w/patch)                               */
+    int32_t patch_k_pad;           /* 3*patch*patch rounded up to a multiple of 64 (zero padded)    */
+    int32_t flags;                 /* IBL_VIT_*                                                     */
+    int32_t n_blocks_run;          /* blocks actually executed (DATOR runs depth-1)                 */
+    int32_t out_dim;               /* dim, or the projection width                                  */
+    float ln_eps;
+} ibl_vit_desc;
+
+typedef struct {                   /* all [dev]; weights bf16 [N][K] row-major (nn.Linear layout)   */
+    const float* ln1_g; const float* ln1_b;
+    const void* w_qkv;  const float* b_qkv;     /* [3*dim][dim] = [Wq; Wk; Wv], [3*dim]              */
+    const void* w_o;    const float* b_o;       /* [dim][dim]                                         */
+    const float* ls1;                            /* [dim] or NULL                                      */
+    const float* ln2_g; const float* ln2_b;
+    const void* w_fc1;  const float* b_fc1;     /* [mlp_dim][dim]                                     */
+    const void* w_fc2;  const float* b_fc2;     /* [dim][mlp_dim]                                     */
+    const float* ls2;
+} ibl_vit_layer;
+
+typedef struct {
+    const void* w_patch;           /* bf16 [dim][patch_k_pad]: conv weight flattened (c, kh, kw)     */
+    const float* b_patch;          /* [dim] or NULL                                                  */
+    const float* cls_pos;          /* [dim]: cls_token + position_embedding[0]                       */
+    const float* pos_patch;        /* [n_tokens-1][dim]: position embeddings of the patch tokens,
+                                      already interpolated to the (img_h/patch, img_w/patch) grid    */
+    const float* ln_pre_g; const float* ln_pre_b;
+    const float* ln_f_g;   const float* ln_f_b;
+    const void* w_proj;            /* bf16 [out_dim][dim] or NULL                                    */
+    ibl_vit_layer layers[IBL_VIT_MAX_LAYERS];
+} ibl_vit_weights;
+
+/* One crop of a preprocessing batch.  The separable resample coefficient tables are the
+ * fixed-point (22-bit) tables of Pillow's 8-bit resampler, computed on the host in float64
+ * (instance-based-loc_amd/preprocess.py) so that the device arithmetic is pure integer and
+ * bit-identical to PIL.Image.resize -- the resize every reference embedding function applies
+ * through its HF / open_clip processor (utils/embeddings.py:41-42, 64-65, 86-89).
+ * Table layout per pass: out_size records of (2 + ksize) int32 = [first_tap, n_taps, k0 .. ]. */
+typedef struct {
+    int64_t src_offset;            /* byte offset of the crop (HWC u8, 3 channels) in `src`          */
+    int32_t in_h, in_w;
+    int32_t h_table, h_ksize;      /* int32 index into `tables` of the horizontal pass, taps/record  */
+    int32_t v_table, v_ksize;      /* vertical pass (NULL pass = identity: ksize 0)                  */
+    int64_t tmp_offset;            /* byte offset of this crop's [in_h][out_w][3] scratch in `tmp`   */
+} ibl_crop_desc;
+
+/* u8 crops -> (optional R<->B swap, utils/embeddings.py:41,64,86) -> PIL-exact resize ->
+ * window (centre crop) -> ((u8/255) - mean) / std -> bf16 im2col patch matrix
+ * [n_crops * (out_h/patch)*(out_w/patch)][patch_k_pad], k = c*patch*patch + kh*patch + kw.
+ *   max_in_h: tallest crop of the batch (sizes the launch);
+ *   src, tables, descs, tmp: [dev];  mean/stdv: 3 floats each (host), indexed by MODEL channel
+ *   out_u8: optional [dev] n_crops x out_h x out_w x 3 resized+cropped u8 image (for parity tests) */
+int ibl_preprocess_crops(const uint8_t* src, const ibl_crop_desc* descs, int n_crops, int max_in_h,
+                         const int32_t* tables,
+                         uint8_t* tmp, int out_h, int out_w, int patch, int patch_k_pad, int swap_rb,
+                         const float* mean, const float* stdv, void* patches, uint8_t* out_u8, void* stream);
+
+/* ViT forward over a batch of crops.  Replaces the batch-1 torch forward of
+ * utils/embeddings.py:46,69,93 and dator/model/backbones/vit_pytorch.py:422-443.
+ *   patches [dev] bf16 [batch*(n_tokens-1)][patch_k_pad] (from ibl_preprocess_crops)
+ *   out     [dev] fp32 [batch][out_dim]  (CLS embedding; un-normalised, like the reference), or
+ *           fp32 [batch][n_tokens][dim] with IBL_VIT_OUT_ALL_TOKENS */
+int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* desc, int batch);
+int ibl_vit_forward(const ibl_vit_desc* desc, const ibl_vit_weights* weights, const void* patches, int batch,
+                    float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* match: L2 normalisation + closest-similarity matrix                 */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -34,6 +34,10 @@ _SIGS = {
     "ibl_closest_similarity_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "ibl_closest_similarity": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, vp, vp, vp,
                                          C.c_int64, vp]),
+    "ibl_preprocess_crops": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       vp, vp, vp, vp, vp]),
+    "ibl_vit_workspace_bytes": (C.c_int64, [vp, C.c_int]),
+    "ibl_vit_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),
     "ibl_assign_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int]),
 }
 

@@ -1,0 +1,551 @@
+// vit.hip -- ViT encoder forward on gfx950 (bf16 MFMA 16x16x32, fp32 accumulate, fp32 residual).
+//
+// Replaces the torch/cuDNN forward the reference reaches through
+//   utils/embeddings.py:46 (CLIP ViT-B/32), :69 (DINOv2), :93 (ViT-B/16), :119 (DATOR streams,
+//   dator/model/backbones/vit_pytorch.py:422-443)
+// one crop at a time; here a whole batch of crops runs per call.
+//
+// HBM layout (all row-major, token-major): residual stream x fp32 [B*T][D]; LayerNorm output,
+// QKV, attention output and MLP hidden as bf16; weights bf16 [N][K] (K contiguous, i.e. the
+// nn.Linear layout) so that both MFMA operands are 16-byte K-contiguous fragments.
+//
+// Kernels: gemm_bf16_tn (128x128x64 LDS-tiled, register-staged double buffer, fused epilogues:
+// bias / bias+GELU / bias*layerscale+residual / patch-embed scatter+pos-embed), layernorm (one
+// wave per row), attention (one workgroup per (crop, head), K and V^T of the head staged in LDS,
+// S^T = K Q^T so that the softmaxed probabilities are already the A operand of P V), CLS/final
+// LayerNorm.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+#include "ibl_common.h"
+#include "ibloc.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short u16;
+
+__device__ __forceinline__ u16 f2bf(float f) {   // round-to-nearest-even, NaN preserved by the hw cvt
+    __hip_bfloat16 b = __float2bfloat16(f);
+    return *reinterpret_cast<u16*>(&b);
+}
+__device__ __forceinline__ float bf2f(u16 h) {
+    unsigned int u = (unsigned int)h << 16;
+    return __uint_as_float(u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C[M][N] = A[M][K] * W[N][K]^T  (+ epilogue)
+// ------------------------------------------------------------------------------------------------
+enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_PATCH_F32 = 3, EPI_BIAS_F32 = 4 };
+
+struct GemmEpi {
+    const float* bias;      // [N] or null
+    const float* scale;     // [N] LayerScale or null (EPI_RESID)
+    const float* pos;       // [P][N] position embedding rows for patches (EPI_PATCH)
+    void* out;              // bf16 or fp32
+    int64_t ldo;            // output row stride (elements)
+    int tokens_per_crop;    // T (EPI_PATCH)
+    int patches_per_crop;   // P (EPI_PATCH)
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int LDS_ROW = GBK * 2 + 16;   // bytes per tile row (128 B of data + 16 B pad)
+
+template <int EPI>
+__global__ __launch_bounds__(256) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
+                                                        int64_t ldw, int M, int N, int K, GemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // buffer b: A tile at (2b) * GBM * LDS_ROW, B tile at (2b + 1) * GBM * LDS_ROW
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware remap: consecutive tiles along N (sharing the A panel) stay on one XCD's L2
+    const int nbn = N / GBN;
+    const int nbm = (M + GBM - 1) / GBM;
+    const int nwg = nbn * nbm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const int row0 = bm * GBM, col0 = bn * GBN;
+
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread
+    int ld_row[4], ld_c16[4];
+    const u16* a_src[4];
+    const u16* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        ld_row[i] = c >> 3;
+        ld_c16[i] = c & 7;
+        int ar = row0 + ld_row[i];
+        if (ar >= M) ar = M - 1;
+        a_src[i] = A + (int64_t)ar * lda + ld_c16[i] * 8;
+        w_src[i] = W + (int64_t)(col0 + ld_row[i]) * ldw + ld_c16[i] * 8;
+    }
+    uint4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (int64_t)kt * GBK);
+            rb[i] = *reinterpret_cast<const uint4*>(w_src[i] + (int64_t)kt * GBK);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(smem + (2 * buf) * GBM * LDS_ROW + ld_row[i] * LDS_ROW + ld_c16[i] * 16) = ra[i];
+            *reinterpret_cast<uint4*>(smem + (2 * buf + 1) * GBM * LDS_ROW + ld_row[i] * LDS_ROW + ld_c16[i] * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / GBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* pa = smem + (2 * buf) * GBM * LDS_ROW + (wm * 64 + fr) * LDS_ROW + fg * 16;
+        const unsigned char* pb = smem + (2 * buf + 1) * GBM * LDS_ROW + (wn * 64 + fr) * LDS_ROW + fg * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * LDS_ROW + ks * 64);
+                bfr[i] = *reinterpret_cast<const bf16x8*>(pb + i * 16 * LDS_ROW + ks * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = col0 + wn * 64 + j * 16 + fr;
+        const float bias = epi.bias ? epi.bias[col] : 0.0f;
+        const float scale = (EPI == EPI_RESID_F32 && epi.scale) ? epi.scale[col] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wm * 64 + i * 16 + fg * 4 + r;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bias;
+                if (EPI == EPI_BIAS_BF16) {
+                    reinterpret_cast<u16*>(epi.out)[(int64_t)row * epi.ldo + col] = f2bf(v);
+                } else if (EPI == EPI_BIAS_GELU_BF16) {
+                    v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                    reinterpret_cast<u16*>(epi.out)[(int64_t)row * epi.ldo + col] = f2bf(v);
+                } else if (EPI == EPI_RESID_F32) {
+                    float* o = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + col;
+                    *o = *o + v * scale;
+                } else if (EPI == EPI_PATCH_F32) {
+                    const int b = row / epi.patches_per_crop, p = row - b * epi.patches_per_crop;
+                    const int64_t orow = (int64_t)b * epi.tokens_per_crop + 1 + p;
+                    reinterpret_cast<float*>(epi.out)[orow * epi.ldo + col] = v + epi.pos[(int64_t)p * N + col];
+                } else {
+                    reinterpret_cast<float*>(epi.out)[(int64_t)row * epi.ldo + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi,
+                       hipStream_t s) {
+    if (M <= 0) return IBL_OK;
+    if (N % GBN != 0 || K % GBK != 0)
+        return ibl_set_error(IBL_ERR_ARG, "gemm: N (%d) must be a multiple of 128 and K (%d) of 64", N, K);
+    const int nwg = (N / GBN) * ((M + GBM - 1) / GBM);
+    const size_t lds = 4 * GBM * LDS_ROW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ibl_gemm_bf16_tn<EPI>, dim3(nwg), dim3(256), lds, s, A, lda, W, ldw, M, N, K, epi);
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, fp32 in -> bf16 out (or fp32 out for the final CLS rows)
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void ibl_layernorm_kernel(const float* x, int64_t in_row_stride,
+                                                            int64_t n_rows, int dim, const float* __restrict__ g,
+                                                            const float* __restrict__ b, float eps, void* out,
+                                                            int64_t out_row_stride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* xr = x + row * in_row_stride;
+    constexpr int MAXV = 4;                 // dim <= 1024
+    float4 v[MAXV];
+    const int nv = dim / 256;               // float4 per lane (dim % 256 == 0 handled; remainder below)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+            v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    const int rem0 = nv * 256;
+    float tail[4] = {0.f, 0.f, 0.f, 0.f};     // up to 255 remaining elements, 4 per lane
+    int ntail = 0;
+    for (int i = rem0 + lane; i < dim; i += 64) { tail[ntail] = xr[i]; s += tail[ntail]; ++ntail; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+            const float a = v[i].x - mean, c = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+            q += a * a + c * c + d * d + e * e;
+        }
+    for (int t = 0; t < ntail; ++t) { const float a = tail[t] - mean; q += a * a; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+            const int c0 = (i * 64 + lane) * 4;
+            const float4 gg = *reinterpret_cast<const float4*>(g + c0);
+            const float4 bb = *reinterpret_cast<const float4*>(b + c0);
+            const float y0 = (v[i].x - mean) * rstd * gg.x + bb.x;
+            const float y1 = (v[i].y - mean) * rstd * gg.y + bb.y;
+            const float y2 = (v[i].z - mean) * rstd * gg.z + bb.z;
+            const float y3 = (v[i].w - mean) * rstd * gg.w + bb.w;
+            if (OUT_F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * out_row_stride + c0) =
+                    make_float4(y0, y1, y2, y3);
+            } else {
+                ushort4 o;
+                o.x = f2bf(y0); o.y = f2bf(y1); o.z = f2bf(y2); o.w = f2bf(y3);
+                *reinterpret_cast<ushort4*>(reinterpret_cast<u16*>(out) + row * out_row_stride + c0) = o;
+            }
+        }
+    int t = 0;
+    for (int i = rem0 + lane; i < dim; i += 64, ++t) {
+        const float y = (tail[t] - mean) * rstd * g[i] + b[i];
+        if (OUT_F32) reinterpret_cast<float*>(out)[row * out_row_stride + i] = y;
+        else reinterpret_cast<u16*>(out)[row * out_row_stride + i] = f2bf(y);
+    }
+}
+
+// x[b*T + 0][:] = cls_pos[:]   (cls token + its position embedding)
+__global__ void ibl_set_cls_kernel(float* __restrict__ x, const float* __restrict__ cls_pos, int B, int T, int dim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * dim) return;
+    const int b = (int)(i / dim), c = (int)(i % dim);
+    x[(int64_t)b * T * dim + c] = cls_pos[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention: one workgroup (4 waves) per (crop, head); head_dim = 64; T <= 16 * NT.
+// qkv bf16 [B*T][3*D] = [q | k | v], each [heads][64].   out bf16 [B*T][D].
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
+                                                            int D, int heads, float scale) {
+    constexpr int KEYS = NT * 16;
+    constexpr int KROW = 144;               // bytes per K row (64 bf16 + 16 B pad)
+    constexpr int VROW = KEYS * 2 + 16;     // bytes per V^T row
+    __shared__ __attribute__((aligned(16))) unsigned char sK[KEYS * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int64_t tok0 = (int64_t)b * T;
+    const int64_t ld = 3 * (int64_t)D;
+    const u16* qbase = qkv + tok0 * ld + h * 64;
+    const u16* kbase = qbase + D;
+    const u16* vbase = qbase + 2 * D;
+
+    // stage K rows (zero beyond T)
+    for (int c = tid; c < KEYS * 8; c += 256) {
+        const int key = c >> 3, c16 = c & 7;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (key < T) val = *reinterpret_cast<const uint4*>(kbase + (int64_t)key * ld + c16 * 8);
+        *reinterpret_cast<uint4*>(sK + key * KROW + c16 * 16) = val;
+    }
+    // stage V transposed: task = (key pair, 8-wide d chunk); writes packed dwords V^T[d][key..key+1]
+    for (int c = tid; c < (KEYS / 2) * 8; c += 256) {
+        const int kp = c % (KEYS / 2), dch = c / (KEYS / 2);
+        const int key = kp * 2;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+        if (key < T) v0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * ld + dch * 8);
+        if (key + 1 < T) v1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)(key + 1) * ld + dch * 8);
+        const unsigned int a[4] = {v0.x, v0.y, v0.z, v0.w}, d[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned int lo = (a[i] & 0xFFFFu) | (d[i] << 16);            // element 2i of both keys
+            const unsigned int hi = (a[i] >> 16) | (d[i] & 0xFFFF0000u);        // element 2i+1
+            *reinterpret_cast<unsigned int*>(sV + (dch * 8 + 2 * i) * VROW + key * 2) = lo;
+            *reinterpret_cast<unsigned int*>(sV + (dch * 8 + 2 * i + 1) * VROW + key * 2) = hi;
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nqt = (T + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        // B operand = Q^T: lane (q = fr, g): Q[q0 + fr][32 ks + 8 g .. +7]
+        int qrow = qt * 16 + fr;
+        if (qrow >= T) qrow = T - 1;
+        const u16* qp = qbase + (int64_t)qrow * ld + fg * 8;
+        const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
+        const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+
+        // S^T tiles: acc[t][r] = S[q = fr][key = 16 t + 4 g + r]
+        f32x4 sc[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const unsigned char* kp = sK + (t * 16 + fr) * KROW + fg * 16;
+            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp);
+            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp + 64);
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 16 + fg * 4 + r;
+                a[r] = key < T ? a[r] * scale : -INFINITY;
+                mx = fmaxf(mx, a[r]);
+            }
+            sc[t] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[t][r] - mx);
+                sc[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+
+        // O = P V : A operand (P) element j of lane (q = fr, g) for k-step s is key
+        //   32 s + 4 g + j (j < 4, tile 2s)   or   32 s + 16 + 4 g + (j - 4) (tile 2s + 1);
+        // B operand (V) uses the same key permutation, read from V^T rows.
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NS = (NT + 1) / 2;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pf[j] = (__bf16)sc[2 * s][j];
+                pf[4 + j] = (2 * s + 1 < NT) ? (__bf16)sc[(2 * s + 1 < NT) ? 2 * s + 1 : 0][j] : (__bf16)0.0f;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const unsigned char* vp = sV + (dt * 16 + fr) * VROW + (32 * s + 4 * fg) * 2;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+                uint2 hi = make_uint2(0, 0);
+                if (2 * s + 1 < NT) hi = *reinterpret_cast<const uint2*>(vp + 32);
+                uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&packed);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+            }
+        }
+        // O layout: row = q = 4 g + r, col = d = fr.  Row sums live on lanes with (lane & 15) == q.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = fg * 4 + r;
+            const float rs = __shfl(sum, q, 64);
+            const int qg = qt * 16 + q;
+            if (qg < T) {
+                const float inv = 1.0f / rs;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    out[(tok0 + qg) * (int64_t)D + h * 64 + dt * 16 + fr] = f2bf(o[dt][r] * inv);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+static inline int64_t rows_pad(int64_t r) { return ibl_align_up(r, 128); }
+
+extern "C" int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* d, int batch) {
+    if (!d || batch <= 0) return -1;
+    const int64_t R = rows_pad((int64_t)batch * d->n_tokens);
+    int64_t bytes = 0;
+    bytes += R * d->dim * 4;          // x
+    bytes += R * d->dim * 2;          // xn
+    bytes += R * 3 * d->dim * 2;      // qkv
+    bytes += R * d->dim * 2;          // attn out
+    bytes += R * d->mlp_dim * 2;      // mlp hidden
+    bytes += rows_pad(batch) * d->dim * 2 + rows_pad(batch) * d->dim * 4;  // final rows (bf16 + f32)
+    return bytes + 6 * 256;
+}
+
+static int run_attention(const u16* qkv, u16* out, int B, int T, int D, int heads, hipStream_t s) {
+    const float scale = 0.125f;   // 1/sqrt(64)
+    const int nt = (T + 15) / 16;
+    dim3 grid(B * heads), block(256);
+#define IBL_ATT(NTV)                                                                                      \
+    hipLaunchKernelGGL(ibl_attention_kernel<NTV>, grid, block, 0, s, qkv, out, T, D, heads, scale)
+    if (nt <= 4) IBL_ATT(4);
+    else if (nt <= 9) IBL_ATT(9);
+    else if (nt <= 13) IBL_ATT(13);
+    else if (nt <= 17) IBL_ATT(17);
+    else return ibl_set_error(IBL_ERR_UNSUPPORTED, "attention: n_tokens %d > 272 not supported", T);
+#undef IBL_ATT
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
+
+extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, const void* patches, int batch,
+                               float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!d || !w || !patches || !out || !workspace) return ibl_set_error(IBL_ERR_ARG, "ibl_vit_forward: null pointer");
+    if (batch <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_vit_forward: batch must be positive");
+    const int D = d->dim, T = d->n_tokens, P = T - 1, H = d->heads;
+    if (D != H * 64) return ibl_set_error(IBL_ERR_UNSUPPORTED, "ibl_vit_forward: head_dim must be 64");
+    if (D % 128 || d->mlp_dim % 128 || d->patch_k_pad % 64 || D > 1024)
+        return ibl_set_error(IBL_ERR_UNSUPPORTED, "ibl_vit_forward: dim/mlp_dim %% 128, patch_k_pad %% 64, dim <= 1024");
+    if (d->n_blocks_run < 0 || d->n_blocks_run > d->depth || d->depth > IBL_VIT_MAX_LAYERS)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_vit_forward: bad depth");
+    if (workspace_bytes < ibl_vit_workspace_bytes(d, batch))
+        return ibl_set_error(IBL_ERR_ARG, "ibl_vit_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t Rn = (int64_t)batch * T, R = rows_pad(Rn);
+
+    auto carve = [](unsigned char*& p, int64_t bytes) {
+        p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255);
+        unsigned char* r = p;
+        p += bytes;
+        return r;
+    };
+    unsigned char* p = reinterpret_cast<unsigned char*>(workspace);
+    float* x = reinterpret_cast<float*>(carve(p, R * D * 4));
+    u16* xn = reinterpret_cast<u16*>(carve(p, R * D * 2));
+    u16* qkv = reinterpret_cast<u16*>(carve(p, R * 3 * D * 2));
+    u16* att = reinterpret_cast<u16*>(carve(p, R * D * 2));
+    u16* hid = reinterpret_cast<u16*>(carve(p, R * d->mlp_dim * 2));
+    u16* fin_bf = reinterpret_cast<u16*>(carve(p, rows_pad(batch) * D * 2));
+
+    int st;
+    // patch embedding (conv as GEMM over im2col'ed patches) + position embedding, scattered into x
+    {
+        GemmEpi e{};
+        e.bias = w->b_patch; e.pos = w->pos_patch; e.out = x; e.ldo = D; e.tokens_per_crop = T; e.patches_per_crop = P;
+        st = launch_gemm<EPI_PATCH_F32>(reinterpret_cast<const u16*>(patches), d->patch_k_pad,
+                                        reinterpret_cast<const u16*>(w->w_patch), d->patch_k_pad, batch * P, D,
+                                        d->patch_k_pad, e, s);
+        if (st) return st;
+        const int64_t n = (int64_t)batch * D;
+        hipLaunchKernelGGL(ibl_set_cls_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w->cls_pos, batch,
+                           T, D);
+        IBL_LAUNCH_CHECK();
+    }
+    const dim3 ln_grid((unsigned)((Rn + 3) / 4));
+    if (d->flags & IBL_VIT_PRE_LN) {
+        // CLIP ln_pre: normalise the residual stream in place (through the bf16-free f32 path)
+        hipLaunchKernelGGL(ibl_layernorm_kernel<true>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, w->ln_pre_g,
+                           w->ln_pre_b, d->ln_eps, (void*)x, (int64_t)D);
+        IBL_LAUNCH_CHECK();
+    }
+    for (int l = 0; l < d->n_blocks_run; ++l) {
+        const ibl_vit_layer* L = &w->layers[l];
+        hipLaunchKernelGGL(ibl_layernorm_kernel<false>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, L->ln1_g,
+                           L->ln1_b, d->ln_eps, (void*)xn, (int64_t)D);
+        IBL_LAUNCH_CHECK();
+        {
+            GemmEpi e{};
+            e.bias = L->b_qkv; e.out = qkv; e.ldo = 3 * D;
+            st = launch_gemm<EPI_BIAS_BF16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv), D, (int)Rn, 3 * D, D, e, s);
+            if (st) return st;
+        }
+        st = run_attention(qkv, att, batch, T, D, H, s);
+        if (st) return st;
+        {
+            GemmEpi e{};
+            e.bias = L->b_o; e.scale = L->ls1; e.out = x; e.ldo = D;
+            st = launch_gemm<EPI_RESID_F32>(att, D, reinterpret_cast<const u16*>(L->w_o), D, (int)Rn, D, D, e, s);
+            if (st) return st;
+        }
+        hipLaunchKernelGGL(ibl_layernorm_kernel<false>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, L->ln2_g,
+                           L->ln2_b, d->ln_eps, (void*)xn, (int64_t)D);
+        IBL_LAUNCH_CHECK();
+        {
+            GemmEpi e{};
+            e.bias = L->b_fc1; e.out = hid; e.ldo = d->mlp_dim;
+            if (d->flags & IBL_VIT_QUICK_GELU)
+                return ibl_set_error(IBL_ERR_UNSUPPORTED, "ibl_vit_forward: QuickGELU not built");
+            st = launch_gemm<EPI_BIAS_GELU_BF16>(xn, D, reinterpret_cast<const u16*>(L->w_fc1), D, (int)Rn, d->mlp_dim, D,
+                                                 e, s);
+            if (st) return st;
+        }
+        {
+            GemmEpi e{};
+            e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = D;
+            st = launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, (int)Rn,
+                                            D, d->mlp_dim, e, s);
+            if (st) return st;
+        }
+    }
+    if (d->flags & IBL_VIT_OUT_ALL_TOKENS) {
+        // DATOR streams: all tokens, optionally through the final LayerNorm
+        if (d->flags & IBL_VIT_FINAL_LN) {
+            hipLaunchKernelGGL(ibl_layernorm_kernel<true>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, w->ln_f_g,
+                               w->ln_f_b, d->ln_eps, (void*)out, (int64_t)D);
+            IBL_LAUNCH_CHECK();
+        } else {
+            IBL_HIP_CHECK(hipMemcpyAsync(out, x, Rn * D * 4, hipMemcpyDeviceToDevice, s));
+        }
+        return IBL_OK;
+    }
+    // CLS rows -> (final LN) -> (projection) -> out fp32 [batch][out_dim]
+    const dim3 cls_grid((unsigned)((batch + 3) / 4));
+    if (d->flags & IBL_VIT_PROJ) {
+        if (!(d->flags & IBL_VIT_FINAL_LN)) return ibl_set_error(IBL_ERR_UNSUPPORTED, "projection needs final LN");
+        hipLaunchKernelGGL(ibl_layernorm_kernel<false>, cls_grid, dim3(256), 0, s, x, (int64_t)T * D, (int64_t)batch, D,
+                           w->ln_f_g, w->ln_f_b, d->ln_eps, (void*)fin_bf, (int64_t)D);
+        IBL_LAUNCH_CHECK();
+        GemmEpi e{};
+        e.bias = nullptr; e.out = out; e.ldo = d->out_dim;
+        return launch_gemm<EPI_BIAS_F32>(fin_bf, D, reinterpret_cast<const u16*>(w->w_proj), D, batch, d->out_dim, D, e, s);
+    }
+    if (d->flags & IBL_VIT_FINAL_LN) {
+        hipLaunchKernelGGL(ibl_layernorm_kernel<true>, cls_grid, dim3(256), 0, s, x, (int64_t)T * D, (int64_t)batch, D,
+                           w->ln_f_g, w->ln_f_b, d->ln_eps, (void*)out, (int64_t)D);
+        IBL_LAUNCH_CHECK();
+    } else {
+        IBL_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)D * 4, x, (size_t)T * D * 4, (size_t)D * 4, batch,
+                                       hipMemcpyDeviceToDevice, s));
+    }
+    return IBL_OK;
+}

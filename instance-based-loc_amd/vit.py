@@ -1,0 +1,302 @@
+"""Host side of the ViT encoders (DINOv2 / ViT-B/16 / CLIP ViT-B/32 / TransReID streams):
+configuration, weight packing into the C-ABI structs of include/ibloc.h, and the batched
+preprocess + forward call.  Replaces the model objects utils/embeddings.py builds at import time
+(/root/reference/utils/embeddings.py:13-28) and the per-crop calls at :31-98.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import preprocess as pp
+
+FLAG_LAYERSCALE = 1
+FLAG_PRE_LN = 2
+FLAG_FINAL_LN = 4
+FLAG_QUICK_GELU = 8
+FLAG_PROJ = 16
+FLAG_OUT_ALL_TOKENS = 32
+MAX_LAYERS = 32
+
+
+class VitDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
+                ("patch", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32), ("n_tokens", C.c_int32),
+                ("patch_k_pad", C.c_int32), ("flags", C.c_int32), ("n_blocks_run", C.c_int32),
+                ("out_dim", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ls1", "ln2_g", "ln2_b",
+                                          "w_fc1", "b_fc1", "w_fc2", "b_fc2", "ls2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_patch", "b_patch", "cls_pos", "pos_patch", "ln_pre_g", "ln_pre_b",
+                                          "ln_f_g", "ln_f_b", "w_proj")] + [("layers", VitLayer * MAX_LAYERS)]
+
+
+@dataclass
+class VitConfig:
+    name: str
+    dim: int
+    depth: int
+    heads: int
+    mlp_dim: int
+    patch: int
+    img_h: int
+    img_w: int
+    pos_grid: tuple            # grid of the stored position embeddings (37, 37) for DINOv2 @518
+    layerscale: bool = False
+    pre_ln: bool = False
+    final_ln: bool = True
+    proj_dim: int = 0
+    ln_eps: float = 1e-6
+    n_blocks_run: int = -1
+    out_all_tokens: bool = False
+    recipe: str = "dinov2"
+    pos_interp: str = "hf-4.44"    # how stored position embeddings are resampled to the run grid
+
+    @property
+    def grid(self):
+        return self.img_h // self.patch, self.img_w // self.patch
+
+    @property
+    def n_tokens(self):
+        return 1 + self.grid[0] * self.grid[1]
+
+    @property
+    def patch_k(self):
+        return 3 * self.patch * self.patch
+
+    @property
+    def patch_k_pad(self):
+        return (self.patch_k + 63) // 64 * 64
+
+    @property
+    def out_dim(self):
+        return self.proj_dim if self.proj_dim else self.dim
+
+
+CONFIGS = {
+    # facebook/dinov2-base, as loaded at utils/embeddings.py:18 (image_size 518 -> 37x37 stored pos-embed)
+    "dinov2_vitb14": VitConfig("dinov2_vitb14", 768, 12, 12, 3072, 14, 224, 224, (37, 37), layerscale=True,
+                               recipe="dinov2"),
+    # facebook/dinov2-small (BASELINE config 1)
+    "dinov2_vits14": VitConfig("dinov2_vits14", 384, 12, 6, 1536, 14, 224, 224, (37, 37), layerscale=True,
+                               recipe="dinov2"),
+    # google/vit-base-patch16-224-in21k (utils/embeddings.py:26), layer_norm_eps 1e-12
+    "vit_b16": VitConfig("vit_b16", 768, 12, 12, 3072, 16, 224, 224, (14, 14), ln_eps=1e-12, recipe="vit"),
+    # open_clip ViT-B-32 laion2b_s34b_b79k (utils/embeddings.py:13-16): ln_pre, ln_post, 512-d projection
+    "clip_b32": VitConfig("clip_b32", 768, 12, 12, 3072, 32, 224, 224, (7, 7), pre_ln=True, proj_dim=512,
+                          ln_eps=1e-5, recipe="clip"),
+    # tiny configurations used by the parity tests
+    "tiny_dino": VitConfig("tiny_dino", 128, 2, 2, 256, 14, 224, 224, (37, 37), layerscale=True, recipe="dinov2"),
+    "tiny_clip": VitConfig("tiny_clip", 128, 2, 2, 256, 32, 224, 224, (7, 7), pre_ln=True, proj_dim=128,
+                           ln_eps=1e-5, recipe="clip"),
+}
+
+
+def random_weights(cfg: VitConfig, seed: int):
+    """Seeded synthetic weights (no pretrained checkpoints exist offline): trunc-normal-ish N(0, 0.02)
+    matrices, LayerNorm gains around 1, LayerScale around 1 -- numpy fp32, keyed like the oracle expects."""
+    rng = np.random.default_rng(seed)
+
+    def mat(*shape, std=0.02):
+        return np.clip(rng.normal(0, std, size=shape), -2 * std, 2 * std).astype(np.float32)
+
+    w = {
+        "patch.w": mat(cfg.dim, 3, cfg.patch, cfg.patch),
+        "patch.b": mat(cfg.dim),
+        "cls": mat(cfg.dim),
+        "pos": mat(1 + cfg.pos_grid[0] * cfg.pos_grid[1], cfg.dim),
+        "ln_f.g": (1 + mat(cfg.dim, std=0.1)),
+        "ln_f.b": mat(cfg.dim, std=0.1),
+    }
+    if cfg.pre_ln:
+        w["ln_pre.g"] = 1 + mat(cfg.dim, std=0.1)
+        w["ln_pre.b"] = mat(cfg.dim, std=0.1)
+    if cfg.proj_dim:
+        w["proj.w"] = mat(cfg.proj_dim, cfg.dim, std=cfg.dim ** -0.5)
+    for l in range(cfg.depth):
+        p = f"l{l}."
+        w[p + "ln1.g"] = 1 + mat(cfg.dim, std=0.1)
+        w[p + "ln1.b"] = mat(cfg.dim, std=0.1)
+        # larger q/k scale than 0.02 so that the attention is not uniform (exercises the softmax)
+        for n in ("q", "k", "v", "o"):
+            w[p + n + ".w"] = mat(cfg.dim, cfg.dim, std=0.06 if n in "qk" else 0.03)
+            w[p + n + ".b"] = mat(cfg.dim, std=0.02)
+        w[p + "ln2.g"] = 1 + mat(cfg.dim, std=0.1)
+        w[p + "ln2.b"] = mat(cfg.dim, std=0.1)
+        w[p + "fc1.w"] = mat(cfg.mlp_dim, cfg.dim, std=0.03)
+        w[p + "fc1.b"] = mat(cfg.mlp_dim)
+        w[p + "fc2.w"] = mat(cfg.dim, cfg.mlp_dim, std=0.02)
+        w[p + "fc2.b"] = mat(cfg.dim)
+        if cfg.layerscale:
+            w[p + "ls1"] = 1 + mat(cfg.dim, std=0.1)
+            w[p + "ls2"] = 1 + mat(cfg.dim, std=0.1)
+    return w
+
+
+def interpolate_pos_embed(pos: np.ndarray, cfg: VitConfig) -> np.ndarray:
+    """Stored (1 + gh*gw, D) position embeddings -> (n_tokens, D) for the run grid.  One-time load step.
+
+    "hf-4.44": transformers 4.44.0 Dinov2Embeddings.interpolate_pos_encoding (the version the reference
+    pins, environment.yml:275): bicubic, align_corners=False, scale_factor = (grid + 0.1) / stored_grid.
+    "size": torch's size= form (transformers >= 4.46)."""
+    gh, gw = cfg.pos_grid
+    th, tw = cfg.grid
+    if (gh, gw) == (th, tw):
+        return pos.astype(np.float32)
+    cls_pos, patch_pos = pos[:1], pos[1:]
+    t = torch.from_numpy(patch_pos.astype(np.float32)).reshape(1, gh, gw, -1).permute(0, 3, 1, 2)
+    if cfg.pos_interp == "hf-4.44":
+        sf = (float((th + 0.1) / math.sqrt(gh * gw)), float((tw + 0.1) / math.sqrt(gh * gw)))
+        t = torch.nn.functional.interpolate(t, scale_factor=sf, mode="bicubic", align_corners=False)
+        if tuple(t.shape[-2:]) != (th, tw):
+            raise ValueError("pos-embed interpolation produced an unexpected grid")
+    else:
+        t = torch.nn.functional.interpolate(t, size=(th, tw), mode="bicubic", align_corners=False)
+    patch_new = t.permute(0, 2, 3, 1).reshape(th * tw, -1).numpy()
+    return np.concatenate([cls_pos, patch_new], axis=0).astype(np.float32)
+
+
+class VitEncoder:
+    """Device-resident weights + batched forward through the C-ABI."""
+
+    def __init__(self, cfg: VitConfig, weights: dict, device="cuda"):
+        if cfg.depth > MAX_LAYERS:
+            raise ValueError("too many layers")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self._keep = []                     # device tensors referenced by the structs
+
+        def dev_f32(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+            self._keep.append(t)
+            return t.data_ptr()
+
+        def dev_bf16(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device).to(torch.bfloat16).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        pos = interpolate_pos_embed(weights["pos"], cfg)
+        wp = np.zeros((cfg.dim, cfg.patch_k_pad), dtype=np.float32)
+        wp[:, :cfg.patch_k] = weights["patch.w"].reshape(cfg.dim, -1)
+        W = VitWeights()
+        W.w_patch = dev_bf16(wp)
+        W.b_patch = dev_f32(weights["patch.b"]) if "patch.b" in weights else None
+        W.cls_pos = dev_f32(weights["cls"].reshape(-1) + pos[0])
+        W.pos_patch = dev_f32(pos[1:])
+        if cfg.pre_ln:
+            W.ln_pre_g, W.ln_pre_b = dev_f32(weights["ln_pre.g"]), dev_f32(weights["ln_pre.b"])
+        if cfg.final_ln:
+            W.ln_f_g, W.ln_f_b = dev_f32(weights["ln_f.g"]), dev_f32(weights["ln_f.b"])
+        if cfg.proj_dim:
+            W.w_proj = dev_bf16(weights["proj.w"])
+        for l in range(cfg.depth):
+            p = f"l{l}."
+            L = W.layers[l]
+            L.ln1_g, L.ln1_b = dev_f32(weights[p + "ln1.g"]), dev_f32(weights[p + "ln1.b"])
+            L.w_qkv = dev_bf16(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0))
+            L.b_qkv = dev_f32(np.concatenate([weights[p + "q.b"], weights[p + "k.b"], weights[p + "v.b"]], axis=0))
+            L.w_o, L.b_o = dev_bf16(weights[p + "o.w"]), dev_f32(weights[p + "o.b"])
+            L.ln2_g, L.ln2_b = dev_f32(weights[p + "ln2.g"]), dev_f32(weights[p + "ln2.b"])
+            L.w_fc1, L.b_fc1 = dev_bf16(weights[p + "fc1.w"]), dev_f32(weights[p + "fc1.b"])
+            L.w_fc2, L.b_fc2 = dev_bf16(weights[p + "fc2.w"]), dev_f32(weights[p + "fc2.b"])
+            if cfg.layerscale:
+                L.ls1, L.ls2 = dev_f32(weights[p + "ls1"]), dev_f32(weights[p + "ls2"])
+        self.W = W
+        flags = 0
+        flags |= FLAG_LAYERSCALE if cfg.layerscale else 0
+        flags |= FLAG_PRE_LN if cfg.pre_ln else 0
+        flags |= FLAG_FINAL_LN if cfg.final_ln else 0
+        flags |= FLAG_PROJ if cfg.proj_dim else 0
+        flags |= FLAG_OUT_ALL_TOKENS if cfg.out_all_tokens else 0
+        nrun = cfg.depth if cfg.n_blocks_run < 0 else cfg.n_blocks_run
+        self.desc = VitDesc(cfg.dim, cfg.depth, cfg.heads, cfg.mlp_dim, cfg.patch, cfg.img_h, cfg.img_w, cfg.n_tokens,
+                            cfg.patch_k_pad, flags, nrun, cfg.out_dim, cfg.ln_eps)
+        self.recipe = pp.RECIPES[cfg.recipe]
+        self._ws = None
+        self._plan_cache = {}
+
+    # ---- preprocessing -------------------------------------------------------------------------
+    def preprocess(self, crops, want_u8=False):
+        """crops: list of HxWx3 uint8 numpy arrays (RGB as the detector hands them over), or a single
+        uint8 device/host tensor (N, H, W, 3) of equally sized crops.  Returns bf16 patch matrix (device)."""
+        r = self.recipe
+        if isinstance(crops, torch.Tensor):
+            n, h, w, _ = crops.shape
+            shapes = [(h, w)] * n
+            src = crops.to(self.device).contiguous().view(-1)
+        else:
+            shapes = [c.shape[:2] for c in crops]
+            src = torch.from_numpy(np.concatenate([np.ascontiguousarray(c, dtype=np.uint8).reshape(-1) for c in crops]))
+            src = src.to(self.device)
+        key = tuple(shapes) if len(set(shapes)) > 1 else (shapes[0], len(shapes))
+        plan = self._plan_cache.get(key)
+        if plan is None:
+            descs, tables, src_bytes, tmp_bytes, max_h = pp.plan_batch(r, shapes)
+            d_descs = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
+            d_tables = torch.from_numpy(tables).to(self.device)
+            plan = (d_descs, d_tables, src_bytes, tmp_bytes, max_h)
+            if len(self._plan_cache) < 64:
+                self._plan_cache[key] = plan
+        d_descs, d_tables, src_bytes, tmp_bytes, max_h = plan
+        assert src.numel() == src_bytes
+        n = len(shapes)
+        P = self.cfg.n_tokens - 1
+        tmp = torch.empty(max(tmp_bytes, 16), dtype=torch.uint8, device=self.device)
+        patches = torch.empty((n * P, self.cfg.patch_k_pad), dtype=torch.bfloat16, device=self.device)
+        out_u8 = torch.empty((n, r.out_h, r.out_w, 3), dtype=torch.uint8, device=self.device) if want_u8 else None
+        mean = (C.c_float * 3)(*r.mean)
+        std = (C.c_float * 3)(*r.std)
+        st = _lib.lib.ibl_preprocess_crops(src.data_ptr(), d_descs.data_ptr(), n, max_h, d_tables.data_ptr(),
+                                           tmp.data_ptr(), r.out_h, r.out_w, self.cfg.patch, self.cfg.patch_k_pad,
+                                           1 if r.swap_rb else 0, mean, std, patches.data_ptr(),
+                                           out_u8.data_ptr() if want_u8 else None,
+                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "ibl_preprocess_crops")
+        return (patches, out_u8) if want_u8 else patches
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward_patches(self, patches: torch.Tensor) -> torch.Tensor:
+        P = self.cfg.n_tokens - 1
+        assert patches.dtype == torch.bfloat16 and patches.is_cuda and patches.shape[1] == self.cfg.patch_k_pad
+        batch = patches.shape[0] // P
+        ws_bytes = _lib.lib.ibl_vit_workspace_bytes(C.byref(self.desc), batch)
+        if self._ws is None or self._ws.numel() < ws_bytes:
+            self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        if self.cfg.out_all_tokens:
+            out = torch.empty((batch, self.cfg.n_tokens, self.cfg.dim), dtype=torch.float32, device=self.device)
+        else:
+            out = torch.empty((batch, self.cfg.out_dim), dtype=torch.float32, device=self.device)
+        st = _lib.lib.ibl_vit_forward(C.byref(self.desc), C.byref(self.W), patches.data_ptr(), batch, out.data_ptr(),
+                                      self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "ibl_vit_forward")
+        return out
+
+    def patches_from_pixels(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, 3, H, W) float model input (already normalised) -> bf16 patch matrix.  Data-layout plumbing
+        only (used by tests and by callers that hold pre-normalised tensors)."""
+        cfg = self.cfg
+        B = x.shape[0]
+        gh, gw = cfg.grid
+        p = cfg.patch
+        t = x.to(self.device, torch.float32).reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5)
+        t = t.reshape(B * gh * gw, 3 * p * p)
+        out = torch.zeros((B * gh * gw, cfg.patch_k_pad), dtype=torch.bfloat16, device=self.device)
+        out[:, :cfg.patch_k] = t.to(torch.bfloat16)
+        return out
+
+    def embed(self, crops, max_batch=512) -> torch.Tensor:
+        """crops -> (N, out_dim) fp32 device tensor (un-normalised CLS embedding, as the reference returns)."""
+        n = crops.shape[0] if isinstance(crops, torch.Tensor) else len(crops)
+        outs = []
+        for i in range(0, n, max_batch):
+            outs.append(self.forward_patches(self.preprocess(crops[i:i + max_batch])))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
