@@ -161,6 +161,38 @@ int ibl_assign_batch(const uint16_t* aug_half, const int32_t* q_per_frame, int n
                      int M, int num_per_length, int32_t* out_assn, int32_t* out_len, int32_t* out_count,
                      int max_assn, int n_threads);
 
+/* ------------------------------------------------------------------------------------------ */
+/* register: grids, normals + FPFH, feature matching, RANSAC, coloured ICP (rows a9-a13)        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Registration context: one device arena (bump allocator) that the batched calls carve their
+ * grids, neighbour lists and per-job state from.  The only persistent device allocation of the
+ * library; created and destroyed explicitly.  Not thread-safe: one context per stream/thread. */
+typedef struct ibl_reg_ctx ibl_reg_ctx;
+int ibl_reg_ctx_create(ibl_reg_ctx** out, int64_t arena_bytes);
+int ibl_reg_ctx_destroy(ibl_reg_ctx* ctx);
+int64_t ibl_reg_ctx_high_water(const ibl_reg_ctx* ctx);
+/* device status word (bit 0: grid table overflow, bit 1: a k-NN query took the re-scan slow path);
+ * synchronises the device */
+int ibl_reg_ctx_status(ibl_reg_ctx* ctx, int clear);
+
+/* Clouds are passed as batches of segments: pts4 [dev] N x float4 (x, y, z, intensity =
+ * (r+g+b)/3), seg_off [dev] and [host] copies of the (n_seg + 1) int32 segment boundaries. */
+
+/* keep[i] = 1 iff the point has more than nb_points points (itself included) within `radius` of its
+ * own cloud.  Replaces PointCloud.remove_radius_outlier (object_memory/object_memory.py:994-995,
+ * utils/depth_utils.py:87-88).  keep: [dev] N bytes. */
+int ibl_radius_outlier_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
+                             int n_seg, double radius, int nb_points, uint8_t* keep, void* stream);
+
+/* Normals (hybrid radius_normal / max_nn_normal, Open3D fast 3x3 eigen solver, no orientation) and
+ * FPFH (hybrid radius_feature / max_nn_feature) of every cloud of the batch.  Replaces
+ * downsample_and_compute_fpfh (utils/fpfh_register.py:86-98).  normals4: [dev] N x float4,
+ * fpfh: [dev] N x 33 fp32 (point-major) or NULL to skip the features. */
+int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
+                           int n_seg, double radius_normal, int max_nn_normal, double radius_feature, int max_nn_feature,
+                           float* normals4, float* fpfh, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

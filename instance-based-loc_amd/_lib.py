@@ -38,6 +38,12 @@ _SIGS = {
                                        vp, vp, vp, vp, vp]),
     "ibl_vit_workspace_bytes": (C.c_int64, [vp, C.c_int]),
     "ibl_vit_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),
+    "ibl_reg_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int64]),
+    "ibl_reg_ctx_destroy": (C.c_int, [vp]),
+    "ibl_reg_ctx_high_water": (C.c_int64, [vp]),
+    "ibl_reg_ctx_status": (C.c_int, [vp, C.c_int]),
+    "ibl_radius_outlier_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp]),
+    "ibl_normals_fpfh_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp]),
     "ibl_assign_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int]),
 }
 

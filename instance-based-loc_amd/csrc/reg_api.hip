@@ -1,0 +1,111 @@
+// reg_api.hip -- C-ABI entry points of the registration path: context (device arena), batched
+// radius-outlier removal and normals + FPFH.  The fused register / evaluate drivers live in
+// reg_register.hip.
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "ibloc.h"
+#include "reg_common.h"
+
+int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
+                       int* status, hipStream_t s);
+int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
+                    float* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
+int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,
+                            unsigned char* keep, hipStream_t s);
+
+extern "C" int ibl_reg_ctx_create(ibl_reg_ctx** out, int64_t arena_bytes) {
+    if (!out || arena_bytes < (1 << 20)) return ibl_set_error(IBL_ERR_ARG, "ibl_reg_ctx_create: bad argument");
+    ibl_reg_ctx* c = new ibl_reg_ctx();
+    IBL_HIP_CHECK(hipGetDevice(&c->device));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->base), (size_t)arena_bytes);
+    if (e != hipSuccess) {
+        delete c;
+        return ibl_set_error(IBL_ERR_HIP, "ibl_reg_ctx_create: hipMalloc(%lld) failed: %s", (long long)arena_bytes, hipGetErrorString(e));
+    }
+    c->size = arena_bytes;
+    // the first 256 bytes hold the device status words
+    c->d_status = reinterpret_cast<int*>(c->base);
+    c->used = 256;
+    e = hipMemset(c->base, 0, 256);
+    if (e != hipSuccess) { (void)hipFree(c->base); delete c; return ibl_set_error(IBL_ERR_HIP, "ibl_reg_ctx_create: memset failed"); }
+    *out = c;
+    return IBL_OK;
+}
+
+extern "C" int ibl_reg_ctx_destroy(ibl_reg_ctx* ctx) {
+    if (!ctx) return IBL_OK;
+    (void)hipFree(ctx->base);
+    delete ctx;
+    return IBL_OK;
+}
+
+extern "C" int64_t ibl_reg_ctx_high_water(const ibl_reg_ctx* ctx) { return ctx ? ctx->high_water : -1; }
+
+extern "C" int ibl_reg_ctx_status(ibl_reg_ctx* ctx, int clear) {
+    if (!ctx) return -1;
+    int h = 0;
+    if (hipMemcpy(&h, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (clear) (void)hipMemset(ctx->d_status, 0, sizeof(int));
+    return h;
+}
+
+static int check_seg(const int32_t* seg_off_host, int n_seg, const char* who) {
+    if (!seg_off_host || n_seg < 0) return ibl_set_error(IBL_ERR_ARG, "%s: bad segment table", who);
+    if (seg_off_host[0] != 0) return ibl_set_error(IBL_ERR_ARG, "%s: seg_off[0] must be 0", who);
+    for (int s = 0; s < n_seg; ++s)
+        if (seg_off_host[s + 1] < seg_off_host[s]) return ibl_set_error(IBL_ERR_ARG, "%s: seg_off must be non-decreasing", who);
+    return IBL_OK;
+}
+
+extern "C" int ibl_radius_outlier_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
+                                        int n_seg, double radius, int nb_points, uint8_t* keep, void* stream) {
+    if (!ctx || !pts4 || !seg_off_dev || !keep || radius <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_radius_outlier_batch: bad argument");
+    int st = check_seg(seg_off_host, n_seg, "ibl_radius_outlier_batch");
+    if (st) return st;
+    ArenaMark mark(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    BatchGrid g;
+    st = ibl_build_batch_grid(ctx, reinterpret_cast<const float4*>(pts4), seg_off_dev, seg_off_host, n_seg, (float)radius,
+                              (int64_t)64 << 20, &g, s);
+    if (st) return st;
+    return ibl_launch_radius_count(g, reinterpret_cast<const float4*>(pts4), seg_off_dev, seg_off_host[n_seg], radius, nb_points, keep, s);
+}
+
+extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
+                                      int n_seg, double radius_normal, int max_nn_normal, double radius_feature, int max_nn_feature,
+                                      float* normals4, float* fpfh, void* stream) {
+    if (!ctx || !pts4 || !seg_off_dev || !normals4 || radius_normal <= 0 || max_nn_normal <= 0)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_normals_fpfh_batch: bad argument");
+    int st = check_seg(seg_off_host, n_seg, "ibl_normals_fpfh_batch");
+    if (st) return st;
+    const int n = seg_off_host[n_seg];
+    ArenaMark mark(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    const float4* P = reinterpret_cast<const float4*>(pts4);
+    {
+        ArenaMark m2(ctx);
+        BatchGrid g;
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)radius_normal, (int64_t)64 << 20, &g, s);
+        if (st) return st;
+        st = ibl_launch_normals(g, P, seg_off_dev, n, radius_normal, max_nn_normal, reinterpret_cast<float4*>(normals4), ctx->d_status, s);
+        if (st) return st;
+    }
+    if (fpfh) {
+        if (radius_feature <= 0 || max_nn_feature <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_normals_fpfh_batch: bad feature parameters");
+        BatchGrid g;
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)radius_feature, (int64_t)64 << 20, &g, s);
+        if (st) return st;
+        float* spfh; int* nbr_idx; float* nbr_d2; int* nbr_cnt;
+        IBL_ARENA(spfh, float, (int64_t)n * 33 + 64);
+        IBL_ARENA(nbr_idx, int, (int64_t)n * max_nn_feature + 64);
+        IBL_ARENA(nbr_d2, float, (int64_t)n * max_nn_feature + 64);
+        IBL_ARENA(nbr_cnt, int, n + 64);
+        st = ibl_launch_fpfh(g, P, reinterpret_cast<const float4*>(normals4), seg_off_dev, n, radius_feature, max_nn_feature, spfh,
+                             nbr_idx, nbr_d2, nbr_cnt, fpfh, ctx->d_status, s);
+        if (st) return st;
+    }
+    return IBL_OK;
+}

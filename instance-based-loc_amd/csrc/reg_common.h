@@ -1,0 +1,221 @@
+// reg_common.h -- shared internals of the registration kernels (grids, context arena, small
+// double-precision linear algebra used on the device).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ibl_common.h"
+
+// One cloud ("segment") of a batch: uniform grid over its bounding box.
+struct SegGrid {
+    float minx, miny, minz, inv;   // inv = 1 / cell size
+    int nx, ny, nz;
+    int cell_base;                 // offset of this segment's cells in the batch-wide cell arrays
+};
+
+// Grid over a batch of clouds: points are sorted by (segment, cell) -- stable, so the candidate
+// enumeration order (and with it every reduction order) is deterministic.
+struct BatchGrid {
+    const SegGrid* seg;        // [S]
+    const int* cell_start;     // [total_cells + 1]
+    const float4* sorted_pts;  // [N] (x, y, z, intensity) in cell order
+    const int* order;          // [N] sorted position -> original point index (batch-global)
+    int n_seg;
+};
+
+// ------------------------------------------------------------------------------------------------
+// context: explicit device arena (bump allocator), created / destroyed through the C-ABI
+// ------------------------------------------------------------------------------------------------
+struct ibl_reg_ctx {
+    unsigned char* base = nullptr;
+    int64_t size = 0;
+    int64_t used = 0;
+    int64_t high_water = 0;
+    int device = 0;
+    int* d_status = nullptr;      // device status word(s): bit flags set by kernels (overflow etc.)
+};
+
+struct ArenaMark {
+    ibl_reg_ctx* ctx;
+    int64_t mark;
+    explicit ArenaMark(ibl_reg_ctx* c) : ctx(c), mark(c->used) {}
+    ~ArenaMark() { ctx->used = mark; }
+};
+
+template <typename T>
+static inline T* arena_alloc(ibl_reg_ctx* ctx, int64_t count, bool* ok) {
+    int64_t bytes = ibl_align_up(count * (int64_t)sizeof(T), 256);
+    if (bytes < 256) bytes = 256;
+    if (ctx->used + bytes > ctx->size) {
+        *ok = false;
+        return nullptr;
+    }
+    T* p = reinterpret_cast<T*>(ctx->base + ctx->used);
+    ctx->used += bytes;
+    if (ctx->used > ctx->high_water) ctx->high_water = ctx->used;
+    return p;
+}
+
+#define IBL_ARENA(ptr, type, count)                                                                  \
+    do {                                                                                             \
+        bool _ok = true;                                                                             \
+        ptr = arena_alloc<type>(ctx, (count), &_ok);                                                 \
+        if (!_ok)                                                                                    \
+            return ibl_set_error(IBL_ERR_ARENA, "device arena exhausted (%lld of %lld bytes used, need %lld more) at %s:%d", \
+                                 (long long)ctx->used, (long long)ctx->size,                         \
+                                 (long long)((count) * (int64_t)sizeof(type)), __FILE__, __LINE__);  \
+    } while (0)
+
+#define IBL_ERR_ARENA (-5)
+#define IBL_ERR_OVERFLOW (-6)
+
+// status bits written by kernels
+#define IBL_ST_GRID_OVERFLOW 1
+#define IBL_ST_KNN_SLOWPATH 2
+
+// grid construction (reg_grid.hip)
+int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
+                         float cell, int64_t max_cells, BatchGrid* out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int seg_of(const int* __restrict__ seg_off, int n_seg, int i) {
+    int lo = 0, hi = n_seg;   // find s with seg_off[s] <= i < seg_off[s+1]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int cell_clamp(float v, float mn, float inv, int n) {
+    int c = (int)floorf((v - mn) * inv);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+__device__ __forceinline__ float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void cross3d(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double dot3d(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ __forceinline__ void xform_d(const double* T, double x, double y, double z, double* o) {
+    o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+    o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+    o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+}
+
+// Philox4x32-10 (counter-based RNG shared with oracle/oracle_reg.c)
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                           unsigned* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---- Kabsch without scaling (Eigen::umeyama semantics): rotation from H = sum (d - dm)(s - sm)^T ----
+__device__ inline void jacobi_eig3_d(double A[3][3], double V[3][3], double* w) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    w[0] = A[0][0]; w[1] = A[1][1]; w[2] = A[2][2];
+}
+
+__device__ inline void rotation_from_H_d(double H[3][3], double R[3][3]) {
+    double HtH[3][3], V[3][3], w[3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += H[k][i] * H[k][j];
+        HtH[i][j] = s;
+    }
+    jacobi_eig3_d(HtH, V, w);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b) if (w[ord[b]] > w[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    double Vs[3][3], U[3][3], sig[3];
+    for (int c = 0; c < 3; ++c) { sig[c] = sqrt(w[ord[c]] > 0 ? w[ord[c]] : 0.0); for (int r = 0; r < 3; ++r) Vs[r][c] = V[r][ord[c]]; }
+    {
+        double c0[3] = {Vs[0][0], Vs[1][0], Vs[2][0]}, c1[3] = {Vs[0][1], Vs[1][1], Vs[2][1]}, c2[3];
+        cross3d(c0, c1, c2);
+        Vs[0][2] = c2[0]; Vs[1][2] = c2[1]; Vs[2][2] = c2[2];
+    }
+    const double tol = 1e-12 * (sig[0] > 0 ? sig[0] : 1.0);
+    int rank = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (sig[c] > tol) {
+            for (int r = 0; r < 3; ++r) U[r][c] = (H[r][0] * Vs[0][c] + H[r][1] * Vs[1][c] + H[r][2] * Vs[2][c]) / sig[c];
+            ++rank;
+        } else break;
+    }
+    if (rank == 0) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = i == j ? 1.0 : 0.0; return; }
+    double u0[3] = {U[0][0], U[1][0], U[2][0]}, u1[3], u2[3];
+    if (rank == 1) {
+        double a[3] = {1, 0, 0};
+        if (fabs(u0[0]) > 0.9) { a[0] = 0; a[1] = 1; }
+        cross3d(u0, a, u1);
+        const double l = sqrt(dot3d(u1, u1)); u1[0] /= l; u1[1] /= l; u1[2] /= l;
+        cross3d(u0, u1, u2);
+    } else {
+        u1[0] = U[0][1]; u1[1] = U[1][1]; u1[2] = U[2][1];
+        const double l0 = sqrt(dot3d(u0, u0)); u0[0] /= l0; u0[1] /= l0; u0[2] /= l0;
+        const double pr = dot3d(u0, u1); u1[0] -= pr * u0[0]; u1[1] -= pr * u0[1]; u1[2] -= pr * u0[2];
+        const double l1 = sqrt(dot3d(u1, u1)); u1[0] /= l1; u1[1] /= l1; u1[2] /= l1;
+        cross3d(u0, u1, u2);
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = u0[i] * Vs[j][0] + u1[i] * Vs[j][1] + u2[i] * Vs[j][2];
+}
+
+// T (row-major 3x4 + [0 0 0 1]) from centroids and H
+__device__ inline void kabsch_from_moments(const double* sm, const double* dm, double H[3][3], double* T) {
+    double R[3][3];
+    rotation_from_H_d(H, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T[4 * r + c] = R[r][c];
+        T[4 * r + 3] = dm[r] - (R[r][0] * sm[0] + R[r][1] * sm[1] + R[r][2] * sm[2]);
+    }
+    T[12] = T[13] = T[14] = 0.0; T[15] = 1.0;
+}
+#endif  // __HIPCC__

@@ -1,0 +1,140 @@
+// reg_grid.hip -- uniform grids over a batch of clouds (one dense grid per cloud), built on the device:
+// bounding boxes -> grid dimensions -> cell ids + histogram -> exclusive scan -> stable radix sort.
+// Replaces the KD-trees Open3D builds inside every estimate_normals / compute_fpfh_feature /
+// registration call of utils/fpfh_register.py:86-150.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "reg_common.h"
+
+// one block per segment: bounding box
+__global__ __launch_bounds__(256) void ibl_bbox_kernel(const float4* __restrict__ pts, const int* __restrict__ seg_off,
+                                                       float* __restrict__ bbox /* [S][6] */) {
+    const int s = blockIdx.x;
+    const int b = seg_off[s], e = seg_off[s + 1];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = b + threadIdx.x; i < e; i += 256) {
+        const float4 p = pts[i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+    __shared__ float smn[3][256], smx[3][256];
+    for (int a = 0; a < 3; ++a) { smn[a][threadIdx.x] = mn[a]; smx[a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (threadIdx.x < st)
+            for (int a = 0; a < 3; ++a) {
+                smn[a][threadIdx.x] = fminf(smn[a][threadIdx.x], smn[a][threadIdx.x + st]);
+                smx[a][threadIdx.x] = fmaxf(smx[a][threadIdx.x], smx[a][threadIdx.x + st]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; ++a) {
+            bbox[s * 6 + a] = e > b ? smn[a][0] : 0.0f;
+            bbox[s * 6 + 3 + a] = e > b ? smx[a][0] : 0.0f;
+        }
+    }
+}
+
+// single block: per-segment grid dimensions and the cell-base prefix (S is small)
+__global__ void ibl_grid_dims_kernel(const float* __restrict__ bbox, int n_seg, float cell, long long max_cells,
+                                     SegGrid* __restrict__ seg, int* __restrict__ total_cells, int* __restrict__ status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long base = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        const float* b = bbox + s * 6;
+        const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+        float c = cell;
+        const float emax = fmaxf(ex, fmaxf(ey, ez));
+        if (emax / 128.0f > c) c = emax / 128.0f;     // bound the table: at most ~129 cells per axis
+        SegGrid g;
+        g.minx = b[0]; g.miny = b[1]; g.minz = b[2];
+        g.inv = 1.0f / c;
+        g.nx = (int)floorf(ex * g.inv) + 1;
+        g.ny = (int)floorf(ey * g.inv) + 1;
+        g.nz = (int)floorf(ez * g.inv) + 1;
+        g.cell_base = (int)base;
+        base += (long long)g.nx * g.ny * g.nz;
+        if (base > max_cells) {
+            atomicOr(status, IBL_ST_GRID_OVERFLOW);
+            g.nx = g.ny = g.nz = 1;                    // keep later kernels in bounds
+            base = g.cell_base + 1;
+        }
+        seg[s] = g;
+    }
+    *total_cells = (int)base;
+}
+
+__global__ __launch_bounds__(256) void ibl_cell_id_kernel(const float4* __restrict__ pts, const int* __restrict__ seg_off, int n_seg,
+                                                          const SegGrid* __restrict__ seg, unsigned* __restrict__ keys,
+                                                          int* __restrict__ vals, int* __restrict__ cell_count) {
+    const int n = seg_off[n_seg];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = seg_of(seg_off, n_seg, i);
+    const SegGrid g = seg[s];
+    const float4 p = pts[i];
+    const int cx = cell_clamp(p.x, g.minx, g.inv, g.nx), cy = cell_clamp(p.y, g.miny, g.inv, g.ny),
+              cz = cell_clamp(p.z, g.minz, g.inv, g.nz);
+    const int c = g.cell_base + (cz * g.ny + cy) * g.nx + cx;
+    keys[i] = (unsigned)c;
+    vals[i] = i;
+    atomicAdd(&cell_count[c], 1);
+}
+
+__global__ __launch_bounds__(256) void ibl_gather_sorted_kernel(const float4* __restrict__ pts, const int* __restrict__ order, int n,
+                                                                float4* __restrict__ sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) sorted[i] = pts[order[i]];
+}
+
+int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
+                         float cell, int64_t max_cells, BatchGrid* out, hipStream_t s) {
+    const int n = seg_off_host[n_seg];
+    float* bbox; SegGrid* seg; int* total; int* cell_count; int* cell_start; unsigned *keys, *keys_out; int *vals, *order;
+    float4* sorted;
+    IBL_ARENA(bbox, float, (int64_t)n_seg * 6 + 6);
+    IBL_ARENA(seg, SegGrid, n_seg + 1);
+    IBL_ARENA(total, int, 4);
+    out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
+    if (n_seg == 0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox);
+    IBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ibl_grid_dims_kernel, dim3(1), dim3(64), 0, s, bbox, n_seg, cell, (long long)max_cells, seg, total,
+                       ctx->d_status);
+    IBL_LAUNCH_CHECK();
+    int h_total = 0;
+    IBL_HIP_CHECK(hipMemcpyAsync(&h_total, total, sizeof(int), hipMemcpyDeviceToHost, s));
+    IBL_HIP_CHECK(hipStreamSynchronize(s));     // the table size decides the scan length (one small read-back per grid)
+    if (h_total <= 0 || h_total > max_cells) return ibl_set_error(IBL_ERR_OVERFLOW, "grid: %d cells exceed the budget %lld", h_total, (long long)max_cells);
+    IBL_ARENA(cell_start, int, (int64_t)h_total + 2);
+    IBL_ARENA(order, int, n + 1);
+    IBL_ARENA(sorted, float4, n + 1);
+    out->cell_start = cell_start; out->sorted_pts = sorted; out->order = order;
+    ArenaMark scratch(ctx);      // everything below is released on return
+    IBL_ARENA(cell_count, int, (int64_t)h_total + 2);
+    IBL_HIP_CHECK(hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)(h_total + 1), s));
+    if (n == 0) {
+        IBL_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)(h_total + 1), s));
+        return IBL_OK;
+    }
+    IBL_ARENA(keys, unsigned, n);
+    IBL_ARENA(keys_out, unsigned, n);
+    IBL_ARENA(vals, int, n);
+    hipLaunchKernelGGL(ibl_cell_id_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, seg_off_dev, n_seg, seg, keys, vals,
+                       cell_count);
+    IBL_LAUNCH_CHECK();
+    size_t tmp_scan = 0, tmp_sort = 0;
+    IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, cell_count, cell_start, h_total + 1, s));
+    int end_bit = 1;
+    while ((1ll << end_bit) < (long long)h_total + 1 && end_bit < 32) ++end_bit;
+    IBL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, keys, keys_out, vals, order, n, 0, end_bit, s));
+    unsigned char* tmp;
+    IBL_ARENA(tmp, unsigned char, (int64_t)(tmp_scan > tmp_sort ? tmp_scan : tmp_sort) + 256);
+    IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_scan, cell_count, cell_start, h_total + 1, s));
+    IBL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, keys, keys_out, vals, order, n, 0, end_bit, s));
+    hipLaunchKernelGGL(ibl_gather_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, order, n, sorted);
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}

@@ -1,0 +1,625 @@
+// reg_knn.hip -- hybrid (radius + k-nearest) neighbourhood kernels on the batch grids and their
+// fused consumers: normals, SPFH/FPFH, colour gradients, radius-outlier counts.
+//
+// Replaces Open3D's KDTreeSearchParamHybrid searches inside
+//   estimate_normals / compute_fpfh_feature          (utils/fpfh_register.py:90-97)
+//   InitializePointCloudForColoredICP                (registration_colored_icp, :132-135)
+//   remove_radius_outlier                            (object_memory/object_memory.py:994-995)
+//
+// One wavefront per query point.  The <= max_nn nearest candidates with d2 < r2 are selected without
+// sorting and without storing the candidate list: pass 1 histograms the in-radius candidates over 256
+// linear d2 bins (LDS, per wave), the bin holding the k-th neighbour is located with a wave scan,
+// pass 2 hands every candidate of a lower bin straight to the consumer and parks only the boundary
+// bin (<= 256 entries) in LDS, where the exact (d2, index) order decides the rest.  Candidate rows are
+// contiguous runs of the cell-sorted point array, read as coalesced float4.  Memory-bound HIP: no
+// MFMA here (normals+FPFH row, HBM roofline).
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+
+#include "reg_common.h"
+
+#define KNN_BINS 256
+#define KNN_CAPB 256
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveLds {
+    int hist[KNN_BINS];
+    unsigned b_bits[KNN_CAPB];
+    int b_idx[KNN_CAPB];
+    int b_j[KNN_CAPB];
+    int scratch[64];
+};
+
+// ------------------------------------------------------------------------------------------------
+// generic driver
+// ------------------------------------------------------------------------------------------------
+template <class Consumer>
+__device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4 q, int qi, float radius, float r2, int max_nn,
+                              WaveLds* L, Consumer& cons, int* status) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int reach = (int)ceilf(radius * sg.inv);
+    if (reach < 1) reach = 1;
+    const int cx = cell_clamp(q.x, sg.minx, sg.inv, sg.nx), cy = cell_clamp(q.y, sg.miny, sg.inv, sg.ny),
+              cz = cell_clamp(q.z, sg.minz, sg.inv, sg.nz);
+    const int x0 = max(cx - reach, 0), x1 = min(cx + reach, sg.nx - 1);
+    const int y0 = max(cy - reach, 0), y1 = min(cy + reach, sg.ny - 1);
+    const int z0 = max(cz - reach, 0), z1 = min(cz + reach, sg.nz - 1);
+    const float bscale = (float)KNN_BINS / r2;
+
+    auto scan = [&](auto&& f) {
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
+                const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+                for (int jb = b; jb < e; jb += 64) {
+                    const int j = jb + lane;
+                    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float d2 = INFINITY;
+                    if (j < e) {
+                        p = g.sorted_pts[j];
+                        d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
+                    }
+                    f(d2 < r2, j, p, d2);
+                }
+            }
+    };
+    auto bin_of = [&](float d2) { int b = (int)(d2 * bscale); return b > KNN_BINS - 1 ? KNN_BINS - 1 : b; };
+
+    // ---- pass 1: histogram --------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 64; ++t) L->hist[lane * (KNN_BINS / 64) + t] = 0;
+    wave_lds_sync();
+    scan([&](bool in, int, const float4&, float d2) {
+        if (in) atomicAdd(&L->hist[bin_of(d2)], 1);
+    });
+    wave_lds_sync();
+    int hb[KNN_BINS / 64];
+    int s = 0;
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 64; ++t) { hb[t] = L->hist[lane * (KNN_BINS / 64) + t]; s += hb[t]; }
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const int cnt = __shfl(incl, 63, 64);
+    const int excl = incl - s;
+    const int k = cnt < max_nn ? cnt : max_nn;
+    bool select_all = cnt <= max_nn;
+    int bstar = KNN_BINS, n_below = 0, pop = 0;
+    if (!select_all) {
+        const unsigned long long m = __ballot(incl >= max_nn);
+        const int Lc = __ffsll((long long)m) - 1;
+        int my_b = 0, my_below = 0, my_pop = 0;
+        {
+            int run = excl;
+#pragma unroll
+            for (int t = 0; t < KNN_BINS / 64; ++t) {
+                if (my_pop == 0 && run + hb[t] >= max_nn) { my_b = lane * (KNN_BINS / 64) + t; my_below = run; my_pop = hb[t]; }
+                run += hb[t];
+            }
+        }
+        bstar = __shfl(my_b, Lc, 64);
+        n_below = __shfl(my_below, Lc, 64);
+        pop = __shfl(my_pop, Lc, 64);
+    }
+    cons.begin(k);
+
+    // ---- pass 2: emit lower bins, park the boundary bin ---------------------------------------
+    const bool fast = pop <= KNN_CAPB;
+    int bcount = 0;
+    scan([&](bool in, int j, const float4& p, float d2) {
+        const int b = in ? bin_of(d2) : KNN_BINS;
+        cons.accept(in && (select_all || b < bstar), j, p, d2);
+        if (!select_all && fast) {
+            const bool park = in && b == bstar;
+            const unsigned long long m = __ballot(park);
+            if (park) {
+                const int pos = bcount + __popcll(m & lt_mask);
+                L->b_bits[pos] = __float_as_uint(d2);
+                L->b_idx[pos] = g.order[j];
+                L->b_j[pos] = j;
+            }
+            bcount += __popcll(m);
+        }
+    });
+    if (!select_all) {
+        const int need = max_nn - n_below;
+        if (fast) {
+            wave_lds_sync();
+            unsigned eb[KNN_CAPB / 64];
+            int ei[KNN_CAPB / 64];
+            bool ev[KNN_CAPB / 64];
+#pragma unroll
+            for (int t = 0; t < KNN_CAPB / 64; ++t) {
+                const int e = lane + 64 * t;
+                ev[t] = e < pop;
+                eb[t] = ev[t] ? L->b_bits[e] : 0xFFFFFFFFu;
+                ei[t] = ev[t] ? L->b_idx[e] : 0x7FFFFFFF;
+            }
+            unsigned lo = 0, hi = 0x7F800000u;
+            while (lo < hi) {
+                const unsigned mid = lo + ((hi - lo) >> 1);
+                int c = 0;
+#pragma unroll
+                for (int t = 0; t < KNN_CAPB / 64; ++t) c += (ev[t] && eb[t] <= mid) ? 1 : 0;
+                c = wave_sum_i(c);
+                if (c >= need) hi = mid; else lo = mid + 1;
+            }
+            const unsigned T = lo;
+            int cl = 0, ct = 0;
+#pragma unroll
+            for (int t = 0; t < KNN_CAPB / 64; ++t) { cl += (ev[t] && eb[t] < T) ? 1 : 0; ct += (ev[t] && eb[t] == T) ? 1 : 0; }
+            cl = wave_sum_i(cl); ct = wave_sum_i(ct);
+            const int need2 = need - cl;
+            int I = 0x7FFFFFFF;
+            if (ct > need2) {
+                int ilo = 0, ihi = 0x7FFFFFFF;
+                while (ilo < ihi) {
+                    const int mid = ilo + ((ihi - ilo) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int t = 0; t < KNN_CAPB / 64; ++t) c += (ev[t] && eb[t] == T && ei[t] <= mid) ? 1 : 0;
+                    c = wave_sum_i(c);
+                    if (c >= need2) ihi = mid; else ilo = mid + 1;
+                }
+                I = ilo;
+            }
+#pragma unroll
+            for (int t = 0; t < KNN_CAPB / 64; ++t) {
+                const bool sel = ev[t] && (eb[t] < T || (eb[t] == T && ei[t] <= I));
+                int j = 0;
+                float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sel) { j = L->b_j[lane + 64 * t]; p = g.sorted_pts[j]; }
+                cons.accept(sel, j, p, __uint_as_float(eb[t]));
+            }
+        } else {
+            // boundary bin larger than the LDS list (many near-equidistant candidates): exact thresholds by
+            // re-scanning the candidates -- slow, correct, flagged in the status word
+            if (lane == 0) atomicOr(status, IBL_ST_KNN_SLOWPATH);
+            unsigned lo = 0, hi = 0x7F800000u;
+            while (lo < hi) {
+                const unsigned mid = lo + ((hi - lo) >> 1);
+                int c = 0;
+                scan([&](bool in, int, const float4&, float d2) {
+                    c += (in && bin_of(d2) == bstar && __float_as_uint(d2) <= mid) ? 1 : 0;
+                });
+                c = wave_sum_i(c);
+                if (c >= need) hi = mid; else lo = mid + 1;
+            }
+            const unsigned T = lo;
+            int cl = 0, ct = 0;
+            scan([&](bool in, int, const float4&, float d2) {
+                const bool bb = in && bin_of(d2) == bstar;
+                cl += (bb && __float_as_uint(d2) < T) ? 1 : 0;
+                ct += (bb && __float_as_uint(d2) == T) ? 1 : 0;
+            });
+            cl = wave_sum_i(cl); ct = wave_sum_i(ct);
+            const int need2 = need - cl;
+            int I = 0x7FFFFFFF;
+            if (ct > need2) {
+                int ilo = 0, ihi = 0x7FFFFFFF;
+                while (ilo < ihi) {
+                    const int mid = ilo + ((ihi - ilo) >> 1);
+                    int c = 0;
+                    scan([&](bool in, int j, const float4&, float d2) {
+                        if (in && bin_of(d2) == bstar && __float_as_uint(d2) == T) c += (g.order[j] <= mid) ? 1 : 0;
+                    });
+                    c = wave_sum_i(c);
+                    if (c >= need2) ihi = mid; else ilo = mid + 1;
+                }
+                I = ilo;
+            }
+            scan([&](bool in, int j, const float4& p, float d2) {
+                bool sel = false;
+                if (in && bin_of(d2) == bstar) {
+                    const unsigned bits = __float_as_uint(d2);
+                    sel = bits < T || (bits == T && g.order[j] <= I);
+                }
+                cons.accept(sel, j, p, d2);
+            });
+        }
+    }
+    cons.finish(k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// robust symmetric 3x3 eigen solver (Open3D FastEigen3x3 / Eberly): smallest-eigenvalue eigenvector
+// ------------------------------------------------------------------------------------------------
+__device__ inline void eigenvector0_d(const double* A, double ev, double* out) {
+    double r0[3] = {A[0] - ev, A[1], A[2]}, r1[3] = {A[1], A[3] - ev, A[4]}, r2[3] = {A[2], A[4], A[5] - ev};
+    double c01[3], c02[3], c12[3];
+    cross3d(r0, r1, c01); cross3d(r0, r2, c02); cross3d(r1, r2, c12);
+    const double d0 = dot3d(c01, c01), d1 = dot3d(c02, c02), d2 = dot3d(c12, c12);
+    double dmax = d0; int imax = 0;
+    if (d1 > dmax) { dmax = d1; imax = 1; }
+    if (d2 > dmax) { imax = 2; }
+    const double* c = imax == 0 ? c01 : (imax == 1 ? c02 : c12);
+    const double d = imax == 0 ? d0 : (imax == 1 ? d1 : d2);
+    const double s = sqrt(d);
+    out[0] = c[0] / s; out[1] = c[1] / s; out[2] = c[2] / s;
+}
+
+__device__ inline void eigenvector1_d(const double* A, const double* e0, double ev1, double* out) {
+    double U[3], V[3];
+    if (fabs(e0[0]) > fabs(e0[1])) {
+        const double inv = 1.0 / sqrt(e0[0] * e0[0] + e0[2] * e0[2]);
+        U[0] = -e0[2] * inv; U[1] = 0; U[2] = e0[0] * inv;
+    } else {
+        const double inv = 1.0 / sqrt(e0[1] * e0[1] + e0[2] * e0[2]);
+        U[0] = 0; U[1] = e0[2] * inv; U[2] = -e0[1] * inv;
+    }
+    cross3d(e0, U, V);
+    double AU[3] = {A[0] * U[0] + A[1] * U[1] + A[2] * U[2], A[1] * U[0] + A[3] * U[1] + A[4] * U[2],
+                    A[2] * U[0] + A[4] * U[1] + A[5] * U[2]};
+    double AV[3] = {A[0] * V[0] + A[1] * V[1] + A[2] * V[2], A[1] * V[0] + A[3] * V[1] + A[4] * V[2],
+                    A[2] * V[0] + A[4] * V[1] + A[5] * V[2]};
+    double m00 = dot3d(U, AU) - ev1, m01 = dot3d(U, AV), m11 = dot3d(V, AV) - ev1;
+    const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        const double mx = a00 > a01 ? a00 : a01;
+        if (mx > 0) {
+            if (a00 >= a01) { m01 /= m00; m00 = 1 / sqrt(1 + m01 * m01); m01 *= m00; }
+            else { m00 /= m01; m01 = 1 / sqrt(1 + m00 * m00); m00 *= m01; }
+            for (int i = 0; i < 3; ++i) out[i] = m01 * U[i] - m00 * V[i];
+        } else { out[0] = U[0]; out[1] = U[1]; out[2] = U[2]; }
+    } else {
+        const double mx = a11 > a01 ? a11 : a01;
+        if (mx > 0) {
+            if (a11 >= a01) { m01 /= m11; m11 = 1 / sqrt(1 + m01 * m01); m01 *= m11; }
+            else { m11 /= m01; m01 = 1 / sqrt(1 + m11 * m11); m11 *= m01; }
+            for (int i = 0; i < 3; ++i) out[i] = m11 * U[i] - m01 * V[i];
+        } else { out[0] = U[0]; out[1] = U[1]; out[2] = U[2]; }
+    }
+}
+
+__device__ inline void fast_eigen_normal_d(const double* cov, double* n) {
+    double mc = cov[0];
+    for (int i = 1; i < 6; ++i) if (cov[i] > mc) mc = cov[i];
+    if (mc == 0) { n[0] = n[1] = n[2] = 0; return; }
+    double A[6];
+    for (int i = 0; i < 6; ++i) A[i] = cov[i] / mc;
+    const double norm = A[1] * A[1] + A[2] * A[2] + A[4] * A[4];
+    if (norm > 0) {
+        const double q = (A[0] + A[3] + A[5]) / 3;
+        const double b00 = A[0] - q, b11 = A[3] - q, b22 = A[5] - q;
+        const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2) / 6);
+        const double c00 = b11 * b22 - A[4] * A[4];
+        const double c01 = A[1] * b22 - A[4] * A[2];
+        const double c02 = A[1] * A[4] - b11 * A[2];
+        const double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+        double half_det = det * 0.5;
+        if (half_det < -1.0) half_det = -1.0;
+        if (half_det > 1.0) half_det = 1.0;
+        const double angle = acos(half_det) / 3.0;
+        const double two_thirds_pi = 2.09439510239319549;
+        const double beta2 = cos(angle) * 2;
+        const double beta0 = cos(angle + two_thirds_pi) * 2;
+        const double beta1 = -(beta0 + beta2);
+        const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+        double v0[3], v1[3], v2[3];
+        if (half_det >= 0) {
+            eigenvector0_d(A, e2, v2);
+            if (e2 < e0 && e2 < e1) { n[0] = v2[0]; n[1] = v2[1]; n[2] = v2[2]; return; }
+            eigenvector1_d(A, v2, e1, v1);
+            if (e1 < e0 && e1 < e2) { n[0] = v1[0]; n[1] = v1[1]; n[2] = v1[2]; return; }
+            cross3d(v1, v2, v0);
+            n[0] = v0[0]; n[1] = v0[1]; n[2] = v0[2];
+        } else {
+            eigenvector0_d(A, e0, v0);
+            if (e0 < e1 && e0 < e2) { n[0] = v0[0]; n[1] = v0[1]; n[2] = v0[2]; return; }
+            eigenvector1_d(A, v0, e1, v1);
+            if (e1 < e0 && e1 < e2) { n[0] = v1[0]; n[1] = v1[1]; n[2] = v1[2]; return; }
+            cross3d(v0, v1, v2);
+            n[0] = v2[0]; n[1] = v2[1]; n[2] = v2[2];
+        }
+    } else {
+        if (cov[0] < cov[3] && cov[0] < cov[5]) { n[0] = 1; n[1] = 0; n[2] = 0; }
+        else if (cov[3] < cov[0] && cov[3] < cov[5]) { n[0] = 0; n[1] = 1; n[2] = 0; }
+        else { n[0] = 0; n[1] = 0; n[2] = 1; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// consumers
+// ------------------------------------------------------------------------------------------------
+struct NormalConsumer {
+    float4* normals;
+    int qi;
+    double c[9];
+    __device__ void begin(int) { for (int t = 0; t < 9; ++t) c[t] = 0.0; }
+    __device__ void accept(bool sel, int, const float4& p, float) {
+        if (sel) {
+            const double x = p.x, y = p.y, z = p.z;
+            c[0] += x; c[1] += y; c[2] += z;
+            c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+        }
+    }
+    __device__ void finish(int k) {
+        for (int t = 0; t < 9; ++t) c[t] = wave_sum_d(c[t]);
+        if ((threadIdx.x & 63) == 0) {
+            double n[3];
+            if (k >= 3) {
+                for (int t = 0; t < 9; ++t) c[t] /= (double)k;
+                double cov[6] = {c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2],
+                                 c[6] - c[1] * c[1], c[7] - c[1] * c[2], c[8] - c[2] * c[2]};
+                fast_eigen_normal_d(cov, n);
+            } else {
+                double cov[6] = {1, 0, 0, 1, 0, 1};
+                fast_eigen_normal_d(cov, n);
+            }
+            if (sqrt(dot3d(n, n)) == 0.0) { n[0] = 0; n[1] = 0; n[2] = 1; }
+            normals[qi] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.0f);
+        }
+    }
+};
+
+__device__ inline void pair_features_d(const float4& p1, const float4& n1f, const float4& p2, const float4& n2f, double* f) {
+    double d[3] = {(double)p2.x - (double)p1.x, (double)p2.y - (double)p1.y, (double)p2.z - (double)p1.z};
+    double n1[3] = {n1f.x, n1f.y, n1f.z}, n2[3] = {n2f.x, n2f.y, n2f.z};
+    const double r = sqrt(dot3d(d, d));
+    f[0] = f[1] = f[2] = 0;
+    if (r == 0.0) return;
+    const double a1 = dot3d(n1, d) / r, a2 = dot3d(n2, d) / r;
+    double na[3], nb[3];
+    // acos(|a1|) > acos(|a2|)  <=>  |a1| < |a2|  (false when either exceeds 1: acos -> NaN)
+    if (fabs(a1) < fabs(a2) && fabs(a1) <= 1.0 && fabs(a2) <= 1.0) {
+        for (int t = 0; t < 3; ++t) { na[t] = n2[t]; nb[t] = n1[t]; d[t] = -d[t]; }
+        f[2] = -a2;
+    } else {
+        for (int t = 0; t < 3; ++t) { na[t] = n1[t]; nb[t] = n2[t]; }
+        f[2] = a1;
+    }
+    double v[3], w[3];
+    cross3d(d, na, v);
+    const double vn = sqrt(dot3d(v, v));
+    if (vn == 0.0) { f[0] = f[1] = f[2] = 0; return; }
+    v[0] /= vn; v[1] /= vn; v[2] /= vn;
+    cross3d(na, v, w);
+    f[1] = dot3d(v, nb);
+    f[0] = atan2(dot3d(w, nb), dot3d(na, nb));
+}
+
+__device__ __forceinline__ int clamp_bin11(int h) { return h < 0 ? 0 : (h >= 11 ? 10 : h); }
+
+struct SpfhConsumer {
+    const float4* normals;   // original order
+    const int* order;
+    float* spfh;             // [N][33]
+    int* nbr_idx;            // [N][K]
+    float* nbr_d2;           // [N][K]
+    int* nbr_cnt;            // [N]
+    int K;
+    int qi;
+    float4 q, qn;
+    int* hist;               // per-wave LDS, 33 ints
+    int ncount;
+    __device__ void begin(int) {
+        const int lane = threadIdx.x & 63;
+        if (lane < 33) hist[lane] = 0;
+        ncount = 0;
+        wave_lds_sync();
+    }
+    __device__ void accept(bool sel, int j, const float4& p, float d2) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int jo = order[j];
+            const int pos = ncount + __popcll(m & ((1ull << lane) - 1ull));
+            nbr_idx[(int64_t)qi * K + pos] = jo;
+            nbr_d2[(int64_t)qi * K + pos] = d2;
+            if (jo != qi) {
+                double f[3];
+                pair_features_d(q, qn, p, normals[jo], f);
+                atomicAdd(&hist[clamp_bin11((int)floor(11 * (f[0] + M_PI) / (2.0 * M_PI)))], 1);
+                atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
+                atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
+            }
+        }
+        ncount += __popcll(m);
+    }
+    __device__ void finish(int k) {
+        const int lane = threadIdx.x & 63;
+        wave_lds_sync();
+        if (lane < 33) {
+            float v = 0.0f;
+            if (k > 1) v = (float)((double)hist[lane] * (100.0 / (double)(k - 1)));
+            spfh[(int64_t)qi * 33 + lane] = v;
+        }
+        if (lane == 0) nbr_cnt[qi] = k;
+    }
+};
+
+struct GradConsumer {
+    const float4* normals;
+    const int* order;
+    const float4* pts;       // original order (for intensity of neighbours use sorted p.w)
+    float4* grad;
+    int qi;
+    float4 q, qn;
+    double a[9];             // AtA (6 unique: 00 01 02 11 12 22) + Atb (3)
+    __device__ void begin(int) { for (int t = 0; t < 9; ++t) a[t] = 0.0; }
+    __device__ void accept(bool sel, int j, const float4& p, float) {
+        if (sel && order[j] != qi) {
+            const double vt[3] = {q.x, q.y, q.z}, nt[3] = {qn.x, qn.y, qn.z};
+            const double dd[3] = {(double)p.x - vt[0], (double)p.y - vt[1], (double)p.z - vt[2]};
+            const double pr = dot3d(dd, nt);
+            const double r[3] = {(double)p.x - pr * nt[0] - vt[0], (double)p.y - pr * nt[1] - vt[1], (double)p.z - pr * nt[2] - vt[2]};
+            const double b = (double)p.w - (double)q.w;
+            a[0] += r[0] * r[0]; a[1] += r[0] * r[1]; a[2] += r[0] * r[2]; a[3] += r[1] * r[1]; a[4] += r[1] * r[2]; a[5] += r[2] * r[2];
+            a[6] += r[0] * b; a[7] += r[1] * b; a[8] += r[2] * b;
+        }
+    }
+    __device__ void finish(int k) {
+        for (int t = 0; t < 9; ++t) a[t] = wave_sum_d(a[t]);
+        if ((threadIdx.x & 63) == 0) {
+            double gx[3] = {0, 0, 0};
+            if (k >= 4) {
+                const double nt[3] = {qn.x, qn.y, qn.z};
+                const double wgt = (double)(k - 1);
+                double M[3][3] = {{a[0], a[1], a[2]}, {a[1], a[3], a[4]}, {a[2], a[4], a[5]}};
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r][c] += wgt * nt[r] * wgt * nt[c];
+                const double B[3] = {a[6], a[7], a[8]};
+                const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                                   M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+                if (det != 0.0 && isfinite(det)) {
+                    gx[0] = (B[0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (B[1] * M[2][2] - M[1][2] * B[2]) +
+                             M[0][2] * (B[1] * M[2][1] - M[1][1] * B[2])) / det;
+                    gx[1] = (M[0][0] * (B[1] * M[2][2] - M[1][2] * B[2]) - B[0] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                             M[0][2] * (M[1][0] * B[2] - B[1] * M[2][0])) / det;
+                    gx[2] = (M[0][0] * (M[1][1] * B[2] - B[1] * M[2][1]) - M[0][1] * (M[1][0] * B[2] - B[1] * M[2][0]) +
+                             B[0] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+                }
+            }
+            grad[qi] = make_float4((float)gx[0], (float)gx[1], (float)gx[2], 0.0f);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ibl_normals_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ seg_off,
+                                                          float radius, float r2, int max_nn, float4* __restrict__ normals, int* status) {
+    __shared__ WaveLds lds[4];
+    const int n = seg_off[g.n_seg];
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= n) return;
+    const int s = seg_of(seg_off, g.n_seg, qi);
+    NormalConsumer cons;
+    cons.normals = normals; cons.qi = qi;
+    hybrid_select(g, g.seg[s], pts[qi], qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
+}
+
+__global__ __launch_bounds__(256) void ibl_spfh_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
+                                                       const int* __restrict__ seg_off, float radius, float r2, int max_nn,
+                                                       float* __restrict__ spfh, int* __restrict__ nbr_idx, float* __restrict__ nbr_d2,
+                                                       int* __restrict__ nbr_cnt, int* status) {
+    __shared__ WaveLds lds[4];
+    const int n = seg_off[g.n_seg];
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= n) return;
+    const int s = seg_of(seg_off, g.n_seg, qi);
+    SpfhConsumer cons;
+    cons.normals = normals; cons.order = g.order; cons.spfh = spfh; cons.nbr_idx = nbr_idx; cons.nbr_d2 = nbr_d2;
+    cons.nbr_cnt = nbr_cnt; cons.K = max_nn; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
+    cons.hist = lds[threadIdx.x >> 6].scratch;
+    hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
+}
+
+// FPFH(i) = 100 * sum_k SPFH(k)/d2_k / blocksum + SPFH(i)   (one wave per point, lanes = bins)
+__global__ __launch_bounds__(256) void ibl_fpfh_kernel(const float* __restrict__ spfh, const int* __restrict__ nbr_idx,
+                                                       const float* __restrict__ nbr_d2, const int* __restrict__ nbr_cnt, int K, int n,
+                                                       float* __restrict__ fpfh) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= n) return;
+    const int k = nbr_cnt[qi];
+    double acc = 0.0;
+    const int b = lane < 33 ? lane : 32;
+    if (k > 1) {
+        for (int t = 0; t < k; ++t) {
+            const int j = nbr_idx[(int64_t)qi * K + t];
+            const double dist = (double)nbr_d2[(int64_t)qi * K + t];
+            if (j == qi || dist == 0.0) continue;
+            acc += (double)spfh[(int64_t)j * 33 + b] / dist;
+        }
+    }
+    // block sums over bins 0-10, 11-21, 22-32 (sequential in bin order, like the reference loop)
+    double sum = 0.0;
+    const int blk = b / 11;
+    for (int t = 0; t < 11; ++t) sum += __shfl(acc, blk * 11 + t, 64);
+    if (lane < 33) {
+        float out = 0.0f;
+        if (k > 1) {
+            const double sc = sum != 0.0 ? 100.0 / sum : 0.0;
+            out = (float)(acc * sc + (double)spfh[(int64_t)qi * 33 + lane]);
+        }
+        fpfh[(int64_t)qi * 33 + lane] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void ibl_color_grad_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
+                                                             const int* __restrict__ seg_off, float radius, float r2, int max_nn,
+                                                             float4* __restrict__ grad, int* status) {
+    __shared__ WaveLds lds[4];
+    const int n = seg_off[g.n_seg];
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= n) return;
+    const int s = seg_of(seg_off, g.n_seg, qi);
+    GradConsumer cons;
+    cons.normals = normals; cons.order = g.order; cons.pts = pts; cons.grad = grad; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
+    hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
+}
+
+// radius outlier: keep[i] = (#points with d2 < r2, self included) > nb_points.  Thread per point, early exit.
+__global__ __launch_bounds__(256) void ibl_radius_count_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ seg_off,
+                                                               float radius, float r2, int nb_points, unsigned char* __restrict__ keep) {
+    const int n = seg_off[g.n_seg];
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= n) return;
+    const SegGrid sg = g.seg[seg_of(seg_off, g.n_seg, qi)];
+    const float4 q = pts[qi];
+    int reach = (int)ceilf(radius * sg.inv);
+    if (reach < 1) reach = 1;
+    const int cx = cell_clamp(q.x, sg.minx, sg.inv, sg.nx), cy = cell_clamp(q.y, sg.miny, sg.inv, sg.ny),
+              cz = cell_clamp(q.z, sg.minz, sg.inv, sg.nz);
+    int cnt = 0;
+    for (int z = max(cz - reach, 0); z <= min(cz + reach, sg.nz - 1) && cnt <= nb_points; ++z)
+        for (int y = max(cy - reach, 0); y <= min(cy + reach, sg.ny - 1) && cnt <= nb_points; ++y) {
+            const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
+            const int b = g.cell_start[row + max(cx - reach, 0)], e = g.cell_start[row + min(cx + reach, sg.nx - 1) + 1];
+            for (int j = b; j < e && cnt <= nb_points; ++j) {
+                const float4 p = g.sorted_pts[j];
+                cnt += dist2f(q.x, q.y, q.z, p.x, p.y, p.z) < r2 ? 1 : 0;
+            }
+        }
+    keep[qi] = cnt > nb_points ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers (used by reg_api.hip)
+// ------------------------------------------------------------------------------------------------
+int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
+                       int* status, hipStream_t s) {
+    if (n <= 0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_normals_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, seg_off, (float)radius,
+                       (float)(radius * radius), max_nn, normals, status);
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
+
+int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
+                    float* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s) {
+    if (n <= 0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_spfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, (float)radius,
+                       (float)(radius * radius), max_nn, spfh, nbr_idx, nbr_d2, nbr_cnt, status);
+    IBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, fpfh);
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
+
+int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius,
+                          int max_nn, float4* grad, int* status, hipStream_t s) {
+    if (n <= 0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_color_grad_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, (float)radius,
+                       (float)(radius * radius), max_nn, grad, status);
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
+
+int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,
+                            unsigned char* keep, hipStream_t s) {
+    if (n <= 0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_radius_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, seg_off, (float)radius,
+                       (float)(radius * radius), nb_points, keep);
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
