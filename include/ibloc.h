@@ -193,6 +193,42 @@ int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* s
                            int n_seg, double radius_normal, int max_nn_normal, double radius_feature, int max_nn_feature,
                            float* normals4, float* fpfh, void* stream);
 
+/* Batched register_point_clouds (utils/fpfh_register.py:100-143) over n_jobs (frame, assignment) jobs.
+ * Job j registers the concatenation of up to three segments of the detected pool (job_src_seg[3j..],
+ * -1 padded) onto the concatenation of up to three segments of the memory pool (job_tgt_seg), exactly
+ * like object_memory/object_memory.py:1023-1034,1087-1089:
+ *   IBL_REG_CENTER      subtract each side's mean first (localise does; the stand-alone function does not)
+ *   IBL_REG_HAVE_COLORS normals + FPFH + RANSAC + coloured ICP; without it the reference's exception path:
+ *                       point-to-point ICP from the identity (fpfh_register.py:137-141)
+ * RANSAC hypothesis i of job j is drawn from Philox4x32-10(counter = (i, job_id_base + j, 0, 0), key = seed).
+ * Outputs are HOST arrays (the call synchronises): T_out [n_jobs][16] row-major double (between the centred
+ * clouds), rmse_out / fitness_out [n_jobs] (result_icp.inlier_rmse / .fitness), means_out [n_jobs][2][3]
+ * (detected mean, memory mean; zeros without IBL_REG_CENTER) or NULL, T_ransac_out [n_jobs][16] or NULL,
+ * ransac_stats_out [n_jobs][3] = (hypotheses walked, validated, best inlier count) or NULL. */
+#define IBL_REG_HAVE_COLORS 1
+#define IBL_REG_CENTER 2
+int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                       int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                       int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs, double voxel_size,
+                       double global_dist_factor, double local_dist_factor, uint64_t seed, uint32_t job_id_base,
+                       int64_t ransac_max_iter, int flags, double* T_out, double* rmse_out, double* fitness_out,
+                       double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, void* stream);
+
+/* Persistent spatial hash over ALL memory points (world frame), built once per memory upload from the
+ * context arena.  Replaces the KD-tree Open3D rebuilds over `all_memory_pcd` on every evaluate_registration
+ * call (utils/fpfh_register.py:146-148 <- object_memory/object_memory.py:1104).  cell >= 2 * threshold keeps a
+ * query to <= 8 cells. */
+typedef struct ibl_memgrid ibl_memgrid;
+int ibl_memgrid_build(ibl_reg_ctx* ctx, const float* mem_pts4, int64_t n, double cell, ibl_memgrid** out, void* stream);
+int ibl_memgrid_destroy(ibl_memgrid* grid);
+
+/* evaluate_transform(all_detected_pcd, all_memory_pcd, T) for n_jobs candidates: job j transforms the detected
+ * points [job_begin[j], job_end[j]) of det_pts4 [dev] by T_global[j] (host, 16 doubles row-major) and looks for
+ * the nearest memory point within `threshold`.  rmse_out / fitness_out: HOST arrays (the call synchronises). */
+int ibl_evaluate_batch(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* det_pts4, const int32_t* job_begin,
+                       const int32_t* job_end, const double* T_global, int n_jobs, double threshold, double* rmse_out,
+                       double* fitness_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -546,12 +546,11 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void ibl_color_grad_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
-                                                             const int* __restrict__ seg_off, float radius, float r2, int max_nn,
-                                                             float4* __restrict__ grad, int* status) {
+                                                             const int* __restrict__ seg_off, int q0, int q1, float radius, float r2,
+                                                             int max_nn, float4* __restrict__ grad, int* status) {
     __shared__ WaveLds lds[4];
-    const int n = seg_off[g.n_seg];
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= n) return;
+    const int qi = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= q1) return;
     const int s = seg_of(seg_off, g.n_seg, qi);
     GradConsumer cons;
     cons.normals = normals; cons.order = g.order; cons.pts = pts; cons.grad = grad; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
@@ -606,10 +605,10 @@ int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals
     return IBL_OK;
 }
 
-int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius,
+int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
                           int max_nn, float4* grad, int* status, hipStream_t s) {
-    if (n <= 0) return IBL_OK;
-    hipLaunchKernelGGL(ibl_color_grad_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, (float)radius,
+    if (q1 <= q0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_color_grad_kernel, dim3((q1 - q0 + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, q0, q1, (float)radius,
                        (float)(radius * radius), max_nn, grad, status);
     IBL_LAUNCH_CHECK();
     return IBL_OK;

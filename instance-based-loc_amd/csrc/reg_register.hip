@@ -1,0 +1,881 @@
+// reg_register.hip -- batched registration of (detected, memory) cloud pairs and scoring against the
+// whole memory: job assembly (concatenate + centre), 33-d feature matching with mutual filter,
+// RANSAC on correspondences, coloured / point-to-point ICP, hash-grid evaluation.
+//
+// Replaces, for a whole batch of (frame, assignment) jobs at once,
+//   object_memory/object_memory.py:1023-1034   concatenate the chosen clouds, subtract each side's mean
+//   utils/fpfh_register.py:100-143            register_point_clouds (Open3D RANSAC + coloured ICP, p2p fallback)
+//   utils/fpfh_register.py:145-150            evaluate_transform against the concatenation of all memory clouds
+// RANSAC follows the index-ordered, Philox-driven semantics of oracle/oracle_reg.c (Open3D's own loop is
+// unseeded and OpenMP-racy): hypotheses are generated and scored in parallel rounds, then folded by a
+// sequential scan that reproduces the "better result / confidence-based early exit" bookkeeping exactly.
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "ibloc.h"
+#include "reg_common.h"
+
+int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
+                       int* status, hipStream_t s);
+int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
+                    float* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
+int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
+                          int max_nn, float4* grad, int* status, hipStream_t s);
+
+#define HB 4096          // RANSAC hypotheses per job per round
+#define ICP_BPJ 32       // blocks per job in the ICP / evaluation reductions
+#define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
+
+// ------------------------------------------------------------------------------------------------
+// job assembly
+// ------------------------------------------------------------------------------------------------
+struct JobDesc {             // host-built, copied to the device
+    int src_seg[3];          // segments of the detected pool (-1 = unused)
+    int tgt_seg[3];          // segments of the memory pool
+};
+
+// grid (J, 2): mean of the concatenated clouds in double
+__global__ __launch_bounds__(256) void ibl_job_mean_kernel(const JobDesc* __restrict__ jobs, const float4* __restrict__ det,
+                                                           const int* __restrict__ det_off, const float4* __restrict__ mem,
+                                                           const int* __restrict__ mem_off, int center, double* __restrict__ means /* [J][2][3] */) {
+    const int j = blockIdx.x, side = blockIdx.y;
+    const float4* pool = side == 0 ? det : mem;
+    const int* off = side == 0 ? det_off : mem_off;
+    double sx = 0, sy = 0, sz = 0;
+    long long cnt = 0;
+    for (int t = 0; t < 3; ++t) {
+        const int sg = side == 0 ? jobs[j].src_seg[t] : jobs[j].tgt_seg[t];
+        if (sg < 0) continue;
+        const int b = off[sg], e = off[sg + 1];
+        cnt += e - b;
+        for (int i = b + threadIdx.x; i < e; i += 256) { const float4 p = pool[i]; sx += p.x; sy += p.y; sz += p.z; }
+    }
+    __shared__ double sh[3][256];
+    sh[0][threadIdx.x] = sx; sh[1][threadIdx.x] = sy; sh[2][threadIdx.x] = sz;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (threadIdx.x < st) for (int a = 0; a < 3; ++a) sh[a][threadIdx.x] += sh[a][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int a = 0; a < 3; ++a) means[(j * 2 + side) * 3 + a] = (center && cnt > 0) ? sh[a][0] / (double)cnt : 0.0;
+}
+
+// writes the centred job clouds: segments [0, J) = sources, [J, 2J) = targets
+__global__ __launch_bounds__(256) void ibl_job_gather_kernel(const JobDesc* __restrict__ jobs, int J, const float4* __restrict__ det,
+                                                             const int* __restrict__ det_off, const float4* __restrict__ mem,
+                                                             const int* __restrict__ mem_off, const int* __restrict__ job_off /* [2J+1] */,
+                                                             const double* __restrict__ means, float4* __restrict__ out) {
+    const int n = job_off[2 * J];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int sgi = seg_of(job_off, 2 * J, i);
+    const int side = sgi >= J ? 1 : 0, j = side ? sgi - J : sgi;
+    int local = i - job_off[sgi];
+    const float4* pool = side == 0 ? det : mem;
+    const int* off = side == 0 ? det_off : mem_off;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < 3; ++t) {
+        const int sg = side == 0 ? jobs[j].src_seg[t] : jobs[j].tgt_seg[t];
+        if (sg < 0) continue;
+        const int len = off[sg + 1] - off[sg];
+        if (local < len) { p = pool[off[sg] + local]; break; }
+        local -= len;
+    }
+    const double* m = means + (j * 2 + side) * 3;
+    out[i] = make_float4((float)((double)p.x - m[0]), (float)((double)p.y - m[1]), (float)((double)p.z - m[2]), p.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature matching: 1-NN in 33-d (fp32 fmaf chain k = 0..32, first minimum wins), both directions
+// grid (tiles, 2J): y < J: queries = source j, database = target j;  y >= J: the reverse
+// ------------------------------------------------------------------------------------------------
+#define FT_TILE 32
+__global__ __launch_bounds__(256) void ibl_feat_nn_kernel(const float* __restrict__ feat, const int* __restrict__ job_off, int J,
+                                                          int* __restrict__ nn /* [N]: database-local index */) {
+    const int qs = blockIdx.y;
+    const int ds = qs < J ? qs + J : qs - J;
+    const int qb = job_off[qs], qe = job_off[qs + 1], db = job_off[ds], de = job_off[ds + 1];
+    const int q0 = qb + blockIdx.x * 256;
+    if (q0 >= qe) return;
+    const int qi = q0 + threadIdx.x;
+    const bool valid = qi < qe;
+    float f[33];
+    {
+        const float* src = feat + (int64_t)(valid ? qi : qe - 1) * 33;
+#pragma unroll
+        for (int k = 0; k < 33; ++k) f[k] = src[k];
+    }
+    __shared__ float tile[FT_TILE * 33];
+    float best = INFINITY;
+    int bj = 0;
+    for (int t0 = db; t0 < de; t0 += FT_TILE) {
+        const int nt = min(FT_TILE, de - t0);
+        __syncthreads();
+        for (int x = threadIdx.x; x < nt * 33; x += 256) tile[x] = feat[(int64_t)t0 * 33 + x];
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 33; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
+            if (acc < best) { best = acc; bj = t0 - db + t; }
+        }
+    }
+    if (valid) nn[qi] = bj;
+}
+
+// one block per job: mutual filter + ordered compaction; falls back to all source->target matches when fewer than
+// 3 * ransac_n survive (Open3D RegistrationRANSACBasedOnFeatureMatching)
+__global__ __launch_bounds__(256) void ibl_mutual_kernel(const int* __restrict__ nn, const int* __restrict__ job_off, int J, int mutual,
+                                                         int min_mutual, int2* __restrict__ corr /* capacity: source offsets */,
+                                                         int* __restrict__ n_corr) {
+    const int j = blockIdx.x;
+    const int sb = job_off[j], se = job_off[j + 1], tb = job_off[J + j], te = job_off[J + j + 1];
+    const int ns = se - sb, nt = te - tb;
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    if (ns == 0 || nt == 0) { if (threadIdx.x == 0) n_corr[j] = 0; return; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (mutual) {
+        for (int i0 = 0; i0 < ns; i0 += 256) {
+            const int i = i0 + threadIdx.x;
+            bool keep = false;
+            int tj = 0;
+            if (i < ns) { tj = nn[sb + i]; keep = nn[tb + tj] == i; }
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) wave_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int pre = base;
+            for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
+            if (keep) corr[sb + pre + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(i, tj);
+            __syncthreads();
+            if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
+        }
+        if (base >= min_mutual) { if (threadIdx.x == 0) n_corr[j] = base; return; }
+    }
+    for (int i = threadIdx.x; i < ns; i += 256) corr[sb + i] = make_int2(i, nn[sb + i]);
+    if (threadIdx.x == 0) n_corr[j] = ns;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RANSAC
+// ------------------------------------------------------------------------------------------------
+struct RansacState {
+    double best_T[16];
+    double best_fit, best_rmse;
+    long long est_k, next_i, walked, validated;
+    int best_inl;
+    int done;
+};
+
+__global__ void ibl_ransac_init_kernel(RansacState* __restrict__ st, const int* __restrict__ n_corr, int J, long long max_iter,
+                                       double max_dist) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    RansacState s;
+    for (int i = 0; i < 16; ++i) s.best_T[i] = (i % 5) == 0 ? 1.0 : 0.0;
+    s.best_fit = 0; s.best_rmse = 0; s.est_k = max_iter; s.next_i = 0; s.walked = 0; s.validated = 0; s.best_inl = 0;
+    s.done = (n_corr[j] < 3 || max_dist <= 0) ? 1 : 0;
+    st[j] = s;
+}
+
+// thread per (job, slot): draw, edge-length check, Kabsch, distance check
+__global__ __launch_bounds__(256) void ibl_ransac_hyp_kernel(const RansacState* __restrict__ st, const float4* __restrict__ pts,
+                                                             const int* __restrict__ job_off, int J, const int2* __restrict__ corr,
+                                                             const int* __restrict__ n_corr, double max_dist, double edge_sim,
+                                                             unsigned seed_lo, unsigned seed_hi, unsigned job_id_base,
+                                                             double* __restrict__ hyp_T /* [J][HB][12] */,
+                                                             unsigned char* __restrict__ hyp_valid /* [J][HB] */) {
+    const int j = blockIdx.y;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const RansacState& S = st[j];
+    unsigned char ok = 0;
+    const long long i = S.next_i + slot;
+    if (!S.done && i < S.est_k) {
+        const int nc = n_corr[j];
+        const int sb = job_off[j], tb = job_off[J + j];
+        unsigned r[4];
+        philox4x32((unsigned)i, job_id_base + (unsigned)j, (unsigned)((unsigned long long)i >> 32), 0u, seed_lo, seed_hi, r);
+        double s[9], d[9];
+        for (int t = 0; t < 3; ++t) {
+            const int pick = (int)(((unsigned long long)r[t] * (unsigned long long)nc) >> 32);
+            const int2 c = corr[sb + pick];
+            const float4 ps = pts[sb + c.x], pd = pts[tb + c.y];
+            s[3 * t] = ps.x; s[3 * t + 1] = ps.y; s[3 * t + 2] = ps.z;
+            d[3 * t] = pd.x; d[3 * t + 1] = pd.y; d[3 * t + 2] = pd.z;
+        }
+        ok = 1;
+        for (int a = 0; a < 3 && ok; ++a)
+            for (int b = a + 1; b < 3; ++b) {
+                const double ds = sqrt((s[3 * a] - s[3 * b]) * (s[3 * a] - s[3 * b]) + (s[3 * a + 1] - s[3 * b + 1]) * (s[3 * a + 1] - s[3 * b + 1]) +
+                                       (s[3 * a + 2] - s[3 * b + 2]) * (s[3 * a + 2] - s[3 * b + 2]));
+                const double dt = sqrt((d[3 * a] - d[3 * b]) * (d[3 * a] - d[3 * b]) + (d[3 * a + 1] - d[3 * b + 1]) * (d[3 * a + 1] - d[3 * b + 1]) +
+                                       (d[3 * a + 2] - d[3 * b + 2]) * (d[3 * a + 2] - d[3 * b + 2]));
+                if (ds < dt * edge_sim || dt < ds * edge_sim) { ok = 0; break; }
+            }
+        if (ok) {
+            double sm[3] = {0, 0, 0}, dm[3] = {0, 0, 0};
+            for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) { sm[a] += s[3 * t + a]; dm[a] += d[3 * t + a]; }
+            for (int a = 0; a < 3; ++a) { sm[a] /= 3; dm[a] /= 3; }
+            double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int t = 0; t < 3; ++t)
+                for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) H[rr][cc] += (d[3 * t + rr] - dm[rr]) * (s[3 * t + cc] - sm[cc]);
+            double T[16];
+            kabsch_from_moments(sm, dm, H, T);
+            for (int t = 0; t < 3 && ok; ++t) {
+                double p[3];
+                xform_d(T, s[3 * t], s[3 * t + 1], s[3 * t + 2], p);
+                const double dx = p[0] - d[3 * t], dy = p[1] - d[3 * t + 1], dz = p[2] - d[3 * t + 2];
+                if (sqrt(dx * dx + dy * dy + dz * dz) > max_dist) ok = 0;
+            }
+            if (ok) {
+                double* o = hyp_T + ((int64_t)j * HB + slot) * 12;
+                for (int t = 0; t < 12; ++t) o[t] = T[t];
+            }
+        }
+    }
+    hyp_valid[(int64_t)j * HB + slot] = ok;
+}
+
+// wave per (job, slot): validation on the correspondence set
+__global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const float4* __restrict__ pts, const int* __restrict__ job_off, int J,
+                                                               const int2* __restrict__ corr, const int* __restrict__ n_corr, double max_dist,
+                                                               const double* __restrict__ hyp_T, const unsigned char* __restrict__ hyp_valid,
+                                                               int* __restrict__ hyp_inl, double* __restrict__ hyp_err2) {
+    const int j = blockIdx.y;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (!hyp_valid[(int64_t)j * HB + slot]) return;
+    double T[12];
+    for (int t = 0; t < 12; ++t) T[t] = hyp_T[((int64_t)j * HB + slot) * 12 + t];
+    const int nc = n_corr[j], sb = job_off[j], tb = job_off[J + j];
+    int inl = 0;
+    double err2 = 0;
+    for (int c = lane; c < nc; c += 64) {
+        const int2 cc = corr[sb + c];
+        const float4 ps = pts[sb + cc.x], q = pts[tb + cc.y];
+        double p[3];
+        xform_d(T, ps.x, ps.y, ps.z, p);
+        const double dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
+        const double dd = sqrt(dx * dx + dy * dy + dz * dz);
+        if (dd < max_dist) { ++inl; err2 += dd * dd; }
+    }
+    inl = wave_sum_i(inl);
+    err2 = wave_sum_d(err2);
+    if (lane == 0) { hyp_inl[(int64_t)j * HB + slot] = inl; hyp_err2[(int64_t)j * HB + slot] = err2; }
+}
+
+// thread per job: fold the round in hypothesis order
+__global__ void ibl_ransac_scan_kernel(RansacState* __restrict__ st, int J, const int* __restrict__ n_corr, long long max_iter,
+                                       double confidence, const double* __restrict__ hyp_T, const unsigned char* __restrict__ hyp_valid,
+                                       const int* __restrict__ hyp_inl, const double* __restrict__ hyp_err2, int* __restrict__ n_active) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    RansacState S = st[j];
+    if (S.done) return;
+    const int nc = n_corr[j];
+    long long i = S.next_i;
+    const long long end = S.next_i + HB;
+    for (; i < end; ++i) {
+        if (i >= max_iter || i >= S.est_k) { S.done = 1; break; }
+        const int slot = (int)(i - S.next_i);
+        if (!hyp_valid[(int64_t)j * HB + slot]) continue;
+        S.validated++;
+        const int inl = hyp_inl[(int64_t)j * HB + slot];
+        const double err2 = hyp_err2[(int64_t)j * HB + slot];
+        const double fit = (double)inl / (double)nc, rmse = inl ? sqrt(err2 / inl) : 0.0;
+        if (inl > 0 && (fit > S.best_fit || (fit == S.best_fit && rmse < S.best_rmse))) {
+            S.best_fit = fit; S.best_rmse = rmse; S.best_inl = inl;
+            const double* T = hyp_T + ((int64_t)j * HB + slot) * 12;
+            for (int t = 0; t < 12; ++t) S.best_T[t] = T[t];
+            const double ek = log(1.0 - confidence) / log(1.0 - pow(fit, 3.0));
+            if (ek < (double)S.est_k) S.est_k = (long long)ceil(ek);
+        }
+    }
+    S.walked = i;                 // hypotheses walked so far (== the loop index at which the reference loop stands)
+    S.next_i = end;
+    if (!S.done && (end >= max_iter || end >= S.est_k)) S.done = 1;
+    st[j] = S;
+    if (!S.done) atomicAdd(n_active, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ICP (coloured / point-to-point)
+// ------------------------------------------------------------------------------------------------
+struct IcpState {
+    double T[16];
+    double fitness, rmse;
+    int iter, done, started;
+};
+
+__global__ void ibl_icp_init_kernel(IcpState* __restrict__ st, int J, const RansacState* __restrict__ rs, int from_identity) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    IcpState s;
+    for (int i = 0; i < 16; ++i) s.T[i] = (from_identity || !rs) ? ((i % 5) == 0 ? 1.0 : 0.0) : rs[j].best_T[i];
+    s.T[12] = s.T[13] = s.T[14] = 0.0; s.T[15] = 1.0;
+    s.fitness = 0; s.rmse = 0; s.iter = 0; s.done = 0; s.started = 0;
+    st[j] = s;
+}
+
+// nearest target point with d2 < r2 (fp32 distance on the float-rounded query); (d2, index) lexicographic minimum
+__device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, float r2,
+                                         float* d2out) {
+    int reach = (int)ceilf(radius * sg.inv);
+    if (reach < 1) reach = 1;
+    const int cx = (int)floorf((qx - sg.minx) * sg.inv), cy = (int)floorf((qy - sg.miny) * sg.inv), cz = (int)floorf((qz - sg.minz) * sg.inv);
+    int best = -1;
+    float bd = r2;
+    const int x0 = max(cx - reach, 0), x1 = min(cx + reach, sg.nx - 1);
+    if (x1 >= x0)
+        for (int z = max(cz - reach, 0); z <= min(cz + reach, sg.nz - 1); ++z)
+            for (int y = max(cy - reach, 0); y <= min(cy + reach, sg.ny - 1); ++y) {
+                const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
+                const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+                for (int jj = b; jj < e; ++jj) {
+                    const float4 p = g.sorted_pts[jj];
+                    const float d2 = dist2f(qx, qy, qz, p.x, p.y, p.z);
+                    if (d2 < bd) { bd = d2; best = g.order[jj]; }
+                    else if (d2 == bd && best >= 0) { const int o = g.order[jj]; if (o < best) best = o; }
+                }
+            }
+    *d2out = bd;
+    return best;
+}
+
+// grid (ICP_BPJ, J): correspondences under the current T and the normal-equation / Kabsch moments
+__global__ __launch_bounds__(256) void ibl_icp_step_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
+                                                           const float4* __restrict__ grad, const int* __restrict__ job_off, int J,
+                                                           const IcpState* __restrict__ st, float radius, float r2, int colored,
+                                                           double sl_g, double sl_p, double* __restrict__ partial /* [J][BPJ][NACC] */) {
+    const int j = blockIdx.y;
+    const IcpState& S = st[j];
+    if (S.done) return;
+    const int sb = job_off[j], se = job_off[j + 1];
+    const SegGrid sg = g.seg[J + j];
+    double T[12];
+    for (int t = 0; t < 12; ++t) T[t] = S.T[t];
+    double acc[ICP_NACC];
+    for (int t = 0; t < ICP_NACC; ++t) acc[t] = 0.0;
+    for (int i = sb + blockIdx.x * 256 + threadIdx.x; i < se; i += ICP_BPJ * 256) {
+        const float4 s4 = pts[i];
+        double vs[3];
+        xform_d(T, s4.x, s4.y, s4.z, vs);
+        float d2;
+        const int tj = nn_within(g, sg, (float)vs[0], (float)vs[1], (float)vs[2], radius, r2, &d2);
+        if (tj < 0) continue;
+        acc[27] += 1.0;
+        acc[28] += (double)d2;
+        const float4 t4 = pts[tj];
+        const double vt[3] = {t4.x, t4.y, t4.z};
+        if (colored) {
+            const float4 n4 = normals[tj], g4 = grad[tj];
+            const double nt[3] = {n4.x, n4.y, n4.z};
+            double Jr[6], r, c[3];
+            const double dv[3] = {vs[0] - vt[0], vs[1] - vt[1], vs[2] - vt[2]};
+            cross3d(vs, nt, c);
+            Jr[0] = sl_g * c[0]; Jr[1] = sl_g * c[1]; Jr[2] = sl_g * c[2]; Jr[3] = sl_g * nt[0]; Jr[4] = sl_g * nt[1]; Jr[5] = sl_g * nt[2];
+            r = sl_g * dot3d(dv, nt);
+            int q = 0;
+            for (int a = 0; a < 6; ++a) { for (int b = a; b < 6; ++b) acc[q++] += Jr[a] * Jr[b]; }
+            for (int a = 0; a < 6; ++a) acc[21 + a] += Jr[a] * r;
+            const double pr = dot3d(dv, nt);
+            const double vp[3] = {vs[0] - pr * nt[0], vs[1] - pr * nt[1], vs[2] - pr * nt[2]};
+            const double is = s4.w, itg = t4.w;
+            const double dit[3] = {g4.x, g4.y, g4.z};
+            const double dp[3] = {vp[0] - vt[0], vp[1] - vt[1], vp[2] - vt[2]};
+            const double is0 = dot3d(dit, dp) + itg;
+            const double dn = dot3d(dit, nt);
+            const double ditM[3] = {-(dit[0] - dn * nt[0]), -(dit[1] - dn * nt[1]), -(dit[2] - dn * nt[2])};
+            cross3d(vs, ditM, c);
+            Jr[0] = sl_p * c[0]; Jr[1] = sl_p * c[1]; Jr[2] = sl_p * c[2]; Jr[3] = sl_p * ditM[0]; Jr[4] = sl_p * ditM[1]; Jr[5] = sl_p * ditM[2];
+            r = sl_p * (is - is0);
+            q = 0;
+            for (int a = 0; a < 6; ++a) { for (int b = a; b < 6; ++b) acc[q++] += Jr[a] * Jr[b]; }
+            for (int a = 0; a < 6; ++a) acc[21 + a] += Jr[a] * r;
+        } else {
+            for (int a = 0; a < 3; ++a) { acc[a] += vs[a]; acc[3 + a] += vt[a]; }
+            for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) acc[6 + 3 * rr + cc] += vt[rr] * vs[cc];
+        }
+    }
+    __shared__ double sh[4][ICP_NACC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = 0; t < ICP_NACC; ++t) {
+        const double v = wave_sum_d(acc[t]);
+        if (lane == 0) sh[wave][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_NACC)
+        partial[((int64_t)j * ICP_BPJ + blockIdx.x) * ICP_NACC + threadIdx.x] =
+            ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+__device__ inline bool solve6_d(double A[6][6], double* b, double* x) {
+    double M[6][7];
+    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) M[i][j] = A[i][j]; M[i][6] = b[i]; }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        double mx = fabs(M[c][c]);
+        for (int r = c + 1; r < 6; ++r) if (fabs(M[r][c]) > mx) { mx = fabs(M[r][c]); piv = r; }
+        if (mx == 0.0 || !isfinite(mx)) return false;
+        if (piv != c) for (int jj = 0; jj <= 6; ++jj) { const double t = M[c][jj]; M[c][jj] = M[piv][jj]; M[piv][jj] = t; }
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = M[r][c] / M[c][c];
+            for (int jj = c; jj <= 6; ++jj) M[r][jj] -= f * M[c][jj];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = M[i][6];
+        for (int jj = i + 1; jj < 6; ++jj) s -= M[i][jj] * x[jj];
+        x[i] = s / M[i][i];
+    }
+    return true;
+}
+
+// thread per job: finish the reduction, convergence test, Gauss-Newton / Kabsch update
+__global__ void ibl_icp_update_kernel(IcpState* __restrict__ st, int J, const int* __restrict__ job_off, const double* __restrict__ partial,
+                                      int colored, int max_iter, double rel_fitness, double rel_rmse) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    IcpState S = st[j];
+    if (S.done) return;
+    double a[ICP_NACC];
+    for (int t = 0; t < ICP_NACC; ++t) a[t] = 0.0;
+    for (int b = 0; b < ICP_BPJ; ++b)
+        for (int t = 0; t < ICP_NACC; ++t) a[t] += partial[((int64_t)j * ICP_BPJ + b) * ICP_NACC + t];
+    const int ns = job_off[j + 1] - job_off[j];
+    const double cnt = a[27], err2 = a[28];
+    const double nf = ns > 0 ? cnt / (double)ns : 0.0, nr = cnt > 0 ? sqrt(err2 / cnt) : 0.0;
+    if (S.started && fabs(S.fitness - nf) < rel_fitness && fabs(S.rmse - nr) < rel_rmse) {
+        S.fitness = nf; S.rmse = nr; S.done = 1;
+        st[j] = S;
+        return;
+    }
+    S.fitness = nf; S.rmse = nr; S.started = 1;
+    if (S.iter >= max_iter) { S.done = 1; st[j] = S; return; }
+    double U[16];
+    for (int i = 0; i < 16; ++i) U[i] = (i % 5) == 0 ? 1.0 : 0.0;
+    if (cnt > 0) {
+        if (colored) {
+            double A[6][6], nb[6], x[6];
+            int q = 0;
+            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r][c] = a[q]; A[c][r] = a[q]; ++q; }
+            for (int r = 0; r < 6; ++r) nb[r] = -a[21 + r];
+            if (solve6_d(A, nb, x)) {
+                const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+                U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
+                U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
+                U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
+            }
+        } else {
+            double sm[3], dm[3], H[3][3];
+            for (int t = 0; t < 3; ++t) { sm[t] = a[t] / cnt; dm[t] = a[3 + t] / cnt; }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = a[6 + 3 * r + c] - cnt * dm[r] * sm[c];
+            kabsch_from_moments(sm, dm, H, U);
+        }
+    }
+    double R[16];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
+        double s = 0;
+        for (int k = 0; k < 4; ++k) s += U[4 * r + k] * S.T[4 * k + c];
+        R[4 * r + c] = s;
+    }
+    for (int i = 0; i < 16; ++i) S.T[i] = R[i];
+    S.iter++;
+    st[j] = S;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused driver
+// ------------------------------------------------------------------------------------------------
+extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                                  int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                                  int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs, double voxel_size,
+                                  double global_dist_factor, double local_dist_factor, uint64_t seed, uint32_t job_id_base,
+                                  int64_t ransac_max_iter, int flags, double* T_out, double* rmse_out, double* fitness_out,
+                                  double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, void* stream) {
+    if (!ctx || !det_pts4 || !mem_pts4 || !det_off_dev || !mem_off_dev || !det_off_host || !mem_off_host || !job_src_seg || !job_tgt_seg ||
+        !T_out || !rmse_out || !fitness_out)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch: null pointer");
+    if (n_jobs <= 0 || voxel_size <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch: bad sizes");
+    const int J = n_jobs;
+    const bool colored = (flags & IBL_REG_HAVE_COLORS) != 0;
+    const bool center = (flags & IBL_REG_CENTER) != 0;
+    hipStream_t s = (hipStream_t)stream;
+    ArenaMark mark(ctx);
+
+    // ---- host: job table + job cloud offsets ------------------------------------------------------
+    std::vector<JobDesc> jobs(J);
+    std::vector<int> job_off(2 * J + 1, 0);
+    for (int j = 0; j < J; ++j) {
+        int ns = 0, nt = 0;
+        for (int t = 0; t < 3; ++t) {
+            const int a = job_src_seg[3 * j + t], b = job_tgt_seg[3 * j + t];
+            if (a >= n_det_seg || b >= n_mem_seg) return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch: segment index out of range");
+            jobs[j].src_seg[t] = a; jobs[j].tgt_seg[t] = b;
+            if (a >= 0) ns += det_off_host[a + 1] - det_off_host[a];
+            if (b >= 0) nt += mem_off_host[b + 1] - mem_off_host[b];
+        }
+        job_off[j + 1] = ns;          // sizes first, prefix below
+        job_off[J + j + 1] = nt;
+    }
+    for (int i = 0; i < 2 * J; ++i) job_off[i + 1] += job_off[i];
+    const int N = job_off[2 * J], Ns = job_off[J];
+
+    JobDesc* d_jobs; int* d_job_off; double* d_means; float4* P; float4* normals;
+    IBL_ARENA(d_jobs, JobDesc, J);
+    IBL_ARENA(d_job_off, int, 2 * J + 1);
+    IBL_ARENA(d_means, double, (int64_t)J * 6);
+    IBL_ARENA(P, float4, N + 1);
+    IBL_ARENA(normals, float4, N + 1);
+    IBL_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(JobDesc) * J, hipMemcpyHostToDevice, s));
+    IBL_HIP_CHECK(hipMemcpyAsync(d_job_off, job_off.data(), sizeof(int) * (2 * J + 1), hipMemcpyHostToDevice, s));
+    const float4* det = reinterpret_cast<const float4*>(det_pts4);
+    const float4* mem = reinterpret_cast<const float4*>(mem_pts4);
+    hipLaunchKernelGGL(ibl_job_mean_kernel, dim3(J, 2), dim3(256), 0, s, d_jobs, det, det_off_dev, mem, mem_off_dev, center ? 1 : 0, d_means);
+    IBL_LAUNCH_CHECK();
+    if (N > 0) {
+        hipLaunchKernelGGL(ibl_job_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_jobs, J, det, det_off_dev, mem, mem_off_dev,
+                           d_job_off, d_means, P);
+        IBL_LAUNCH_CHECK();
+    }
+    // pageable host copies below are synchronous w.r.t. the stream contents issued so far
+    IBL_HIP_CHECK(hipStreamSynchronize(s));   // job_off / jobs host vectors must outlive their H2D copies
+
+    RansacState* rs = nullptr;
+    IcpState* is;
+    IBL_ARENA(is, IcpState, J);
+    const double max_dist_icp = voxel_size * local_dist_factor;
+    int st;
+
+    // grid A (cell = normal radius) lives until the end: normals, colour gradients, ICP neighbours
+    BatchGrid gA;
+    st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(voxel_size * 2), (int64_t)128 << 20, &gA, s);
+    if (st) return st;
+    float4* grad = nullptr;
+    if (colored) {
+        st = ibl_launch_normals(gA, P, d_job_off, N, voxel_size * 2, 30, normals, ctx->d_status, s);
+        if (st) return st;
+        IBL_ARENA(rs, RansacState, J);
+        int2* corr; int* n_corr;
+        IBL_ARENA(corr, int2, Ns + 1);
+        IBL_ARENA(n_corr, int, J + 1);
+        {
+            // ---- FPFH + matching (scratch released afterwards) ---------------------------------------
+            ArenaMark m2(ctx);
+            BatchGrid gB;
+            st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(voxel_size * 5), (int64_t)64 << 20, &gB, s);
+            if (st) return st;
+            float *spfh, *fpfh, *nbr_d2; int *nbr_idx, *nbr_cnt, *nn;
+            IBL_ARENA(spfh, float, (int64_t)N * 33 + 64);
+            IBL_ARENA(fpfh, float, (int64_t)N * 33 + 64);
+            IBL_ARENA(nbr_idx, int, (int64_t)N * 100 + 64);
+            IBL_ARENA(nbr_d2, float, (int64_t)N * 100 + 64);
+            IBL_ARENA(nbr_cnt, int, N + 64);
+            IBL_ARENA(nn, int, N + 64);
+            st = ibl_launch_fpfh(gB, P, normals, d_job_off, N, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, ctx->d_status, s);
+            if (st) return st;
+            int max_seg = 1;
+            for (int i = 0; i < 2 * J; ++i) max_seg = std::max(max_seg, job_off[i + 1] - job_off[i]);
+            hipLaunchKernelGGL(ibl_feat_nn_kernel, dim3((max_seg + 255) / 256, 2 * J), dim3(256), 0, s, fpfh, d_job_off, J, nn);
+            IBL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ibl_mutual_kernel, dim3(J), dim3(256), 0, s, nn, d_job_off, J, 1, 9, corr, n_corr);
+            IBL_LAUNCH_CHECK();
+        }
+        // ---- RANSAC ----------------------------------------------------------------------------------
+        {
+            ArenaMark m3(ctx);
+            double *hyp_T, *hyp_err2; unsigned char* hyp_valid; int *hyp_inl, *n_active;
+            IBL_ARENA(hyp_T, double, (int64_t)J * HB * 12);
+            IBL_ARENA(hyp_err2, double, (int64_t)J * HB);
+            IBL_ARENA(hyp_inl, int, (int64_t)J * HB);
+            IBL_ARENA(hyp_valid, unsigned char, (int64_t)J * HB);
+            IBL_ARENA(n_active, int, 64);
+            const double max_dist = voxel_size * global_dist_factor;
+            hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist);
+            IBL_LAUNCH_CHECK();
+            const long long max_rounds = (ransac_max_iter + HB - 1) / HB;
+            for (long long round = 0; round < max_rounds; ++round) {
+                hipLaunchKernelGGL(ibl_ransac_hyp_kernel, dim3(HB / 256, J), dim3(256), 0, s, rs, P, d_job_off, J, corr, n_corr, max_dist, 0.9,
+                                   (unsigned)seed, (unsigned)(seed >> 32), job_id_base, hyp_T, hyp_valid);
+                IBL_LAUNCH_CHECK();
+                hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3(HB / 4, J), dim3(256), 0, s, P, d_job_off, J, corr, n_corr, max_dist, hyp_T,
+                                   hyp_valid, hyp_inl, hyp_err2);
+                IBL_LAUNCH_CHECK();
+                IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
+                hipLaunchKernelGGL(ibl_ransac_scan_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99,
+                                   hyp_T, hyp_valid, hyp_inl, hyp_err2, n_active);
+                IBL_LAUNCH_CHECK();
+                if ((round & 3) == 3 || round + 1 == max_rounds || round < 2) {
+                    int h_active = 0;
+                    IBL_HIP_CHECK(hipMemcpyAsync(&h_active, n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+                    IBL_HIP_CHECK(hipStreamSynchronize(s));
+                    if (h_active == 0) break;
+                }
+            }
+        }
+        // ---- colour gradients of the targets --------------------------------------------------------
+        IBL_ARENA(grad, float4, N + 1);
+        st = ibl_launch_color_grad(gA, P, normals, d_job_off, Ns, N, max_dist_icp * 2.0, 30, grad, ctx->d_status, s);
+        if (st) return st;
+    }
+    // ---- ICP ------------------------------------------------------------------------------------------
+    {
+        double* partial;
+        IBL_ARENA(partial, double, (int64_t)J * ICP_BPJ * ICP_NACC);
+        hipLaunchKernelGGL(ibl_icp_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, is, J, rs, colored ? 0 : 1);
+        IBL_LAUNCH_CHECK();
+        const double lambda_geometric = 0.968;
+        const int max_iter = 30;
+        for (int it = 0; it <= max_iter; ++it) {
+            hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, gA, P, normals, grad, d_job_off, J, is,
+                               (float)max_dist_icp, (float)(max_dist_icp * max_dist_icp), colored ? 1 : 0, sqrt(lambda_geometric),
+                               sqrt(1.0 - lambda_geometric), partial);
+            IBL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ibl_icp_update_kernel, dim3((J + 63) / 64), dim3(64), 0, s, is, J, d_job_off, partial, colored ? 1 : 0, max_iter,
+                               1e-6, 1e-6);
+            IBL_LAUNCH_CHECK();
+        }
+    }
+    // ---- results ----------------------------------------------------------------------------------------
+    std::vector<IcpState> h_is(J);
+    IBL_HIP_CHECK(hipMemcpyAsync(h_is.data(), is, sizeof(IcpState) * J, hipMemcpyDeviceToHost, s));
+    std::vector<RansacState> h_rs;
+    if (rs && (T_ransac_out || ransac_stats_out)) {
+        h_rs.resize(J);
+        IBL_HIP_CHECK(hipMemcpyAsync(h_rs.data(), rs, sizeof(RansacState) * J, hipMemcpyDeviceToHost, s));
+    }
+    std::vector<double> h_means((size_t)J * 6);
+    IBL_HIP_CHECK(hipMemcpyAsync(h_means.data(), d_means, sizeof(double) * J * 6, hipMemcpyDeviceToHost, s));
+    IBL_HIP_CHECK(hipStreamSynchronize(s));
+    for (int j = 0; j < J; ++j) {
+        for (int i = 0; i < 16; ++i) T_out[16 * j + i] = h_is[j].T[i];
+        rmse_out[j] = h_is[j].rmse;
+        fitness_out[j] = h_is[j].fitness;
+        if (means_out) for (int i = 0; i < 6; ++i) means_out[6 * j + i] = h_means[6 * j + i];
+        if (T_ransac_out) for (int i = 0; i < 16; ++i) T_ransac_out[16 * j + i] = rs ? h_rs[j].best_T[i] : ((i % 5) == 0 ? 1.0 : 0.0);
+        if (ransac_stats_out) {
+            ransac_stats_out[3 * j] = rs ? h_rs[j].walked : 0;
+            ransac_stats_out[3 * j + 1] = rs ? h_rs[j].validated : 0;
+            ransac_stats_out[3 * j + 2] = rs ? h_rs[j].best_inl : 0;
+        }
+    }
+    return IBL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole-memory hash grid + evaluate_registration
+// ------------------------------------------------------------------------------------------------
+struct ibl_memgrid {
+    float cell, inv;
+    int64_t n;
+    int n_cells;
+    unsigned long long hmask;
+    float4* sorted;                 // points in cell order
+    unsigned long long* ukeys;      // unique cell keys
+    int* ustart;                    // [n_cells + 1]
+    unsigned long long* tkeys;      // hash table keys (EMPTY = ~0)
+    int* tvals;                     // cell index
+};
+
+#define MG_EMPTY 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ unsigned long long mg_key(int ix, int iy, int iz) {
+    return ((unsigned long long)(unsigned)(ix + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(iy + (1 << 20)) << 21) |
+           (unsigned long long)(unsigned)(iz + (1 << 20));
+}
+__device__ __forceinline__ unsigned long long mg_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 33; k *= 0xC4CEB9FE1A85EC53ull; k ^= k >> 33;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void ibl_mg_key_kernel(const float4* __restrict__ pts, int64_t n, float inv, unsigned long long* __restrict__ keys,
+                                                         int* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    keys[i] = mg_key((int)floorf(p.x * inv), (int)floorf(p.y * inv), (int)floorf(p.z * inv));
+    vals[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void ibl_mg_heads_kernel(const unsigned long long* __restrict__ skeys, int64_t n, int* __restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ibl_mg_cells_kernel(const unsigned long long* __restrict__ skeys, const int* __restrict__ head,
+                                                           const int* __restrict__ head_scan, const int* __restrict__ order,
+                                                           const float4* __restrict__ pts, int64_t n, unsigned long long* __restrict__ ukeys,
+                                                           int* __restrict__ ustart, float4* __restrict__ sorted) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    sorted[i] = pts[order[i]];
+    if (head[i]) { const int c = head_scan[i]; ukeys[c] = skeys[i]; ustart[c] = (int)i; }
+}
+
+__global__ __launch_bounds__(256) void ibl_mg_insert_kernel(const unsigned long long* __restrict__ ukeys, int n_cells, unsigned long long hmask,
+                                                            unsigned long long* __restrict__ tkeys, int* __restrict__ tvals) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    const unsigned long long k = ukeys[c];
+    unsigned long long h = mg_hash(k) & hmask;
+    while (true) {
+        const unsigned long long prev = atomicCAS(&tkeys[h], MG_EMPTY, k);
+        if (prev == MG_EMPTY) { tvals[h] = c; return; }
+        h = (h + 1) & hmask;
+    }
+}
+
+extern "C" int ibl_memgrid_build(ibl_reg_ctx* ctx, const float* mem_pts4, int64_t n, double cell, ibl_memgrid** out, void* stream) {
+    if (!ctx || !mem_pts4 || !out || n <= 0 || n > 0x7FFFFFF0ll || cell <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_memgrid_build: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ibl_memgrid* g = new ibl_memgrid();
+    g->cell = (float)cell; g->inv = 1.0f / (float)cell; g->n = n;
+    const float4* P = reinterpret_cast<const float4*>(mem_pts4);
+    // persistent part (stays allocated in the arena until the context is destroyed)
+    IBL_ARENA(g->sorted, float4, n + 1);
+    IBL_ARENA(g->ukeys, unsigned long long, n + 1);
+    IBL_ARENA(g->ustart, int, n + 2);
+    unsigned long long H = 1;
+    while (H < (unsigned long long)n * 2) H <<= 1;
+    g->hmask = H - 1;
+    IBL_ARENA(g->tkeys, unsigned long long, (int64_t)H);
+    IBL_ARENA(g->tvals, int, (int64_t)H);
+    {
+        ArenaMark scratch(ctx);
+        unsigned long long *keys, *skeys; int *vals, *order, *head, *hscan; unsigned char* tmp;
+        IBL_ARENA(keys, unsigned long long, n);
+        IBL_ARENA(skeys, unsigned long long, n);
+        IBL_ARENA(vals, int, n);
+        IBL_ARENA(order, int, n);
+        IBL_ARENA(head, int, n + 1);
+        IBL_ARENA(hscan, int, n + 1);
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(ibl_mg_key_kernel, dim3(nb), dim3(256), 0, s, P, n, g->inv, keys, vals);
+        IBL_LAUNCH_CHECK();
+        size_t t1 = 0, t2 = 0;
+        IBL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, keys, skeys, vals, order, (int)n, 0, 63, s));
+        IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, head, hscan, (int)n, s));
+        IBL_ARENA(tmp, unsigned char, (int64_t)std::max(t1, t2) + 256);
+        IBL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, t1, keys, skeys, vals, order, (int)n, 0, 63, s));
+        hipLaunchKernelGGL(ibl_mg_heads_kernel, dim3(nb), dim3(256), 0, s, skeys, n, head);
+        IBL_LAUNCH_CHECK();
+        IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, t2, head, hscan, (int)n, s));
+        hipLaunchKernelGGL(ibl_mg_cells_kernel, dim3(nb), dim3(256), 0, s, skeys, head, hscan, order, P, n, g->ukeys, g->ustart, g->sorted);
+        IBL_LAUNCH_CHECK();
+        int last_scan = 0, last_head = 0;
+        IBL_HIP_CHECK(hipMemcpyAsync(&last_scan, hscan + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        IBL_HIP_CHECK(hipMemcpyAsync(&last_head, head + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        IBL_HIP_CHECK(hipStreamSynchronize(s));
+        g->n_cells = last_scan + last_head;
+        const int nn = (int)n;
+        IBL_HIP_CHECK(hipMemcpyAsync(g->ustart + g->n_cells, &nn, sizeof(int), hipMemcpyHostToDevice, s));
+        IBL_HIP_CHECK(hipMemsetAsync(g->tkeys, 0xFF, sizeof(unsigned long long) * H, s));
+        hipLaunchKernelGGL(ibl_mg_insert_kernel, dim3((g->n_cells + 255) / 256), dim3(256), 0, s, g->ukeys, g->n_cells, g->hmask, g->tkeys,
+                           g->tvals);
+        IBL_LAUNCH_CHECK();
+        IBL_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    *out = g;
+    return IBL_OK;
+}
+
+extern "C" int ibl_memgrid_destroy(ibl_memgrid* g) {
+    delete g;       // device memory belongs to the context arena
+    return IBL_OK;
+}
+
+struct EvalJob {
+    double T[12];
+    int begin, end;      // detected point range (all cleaned detected clouds of the job's frame)
+};
+
+// grid (ICP_BPJ, J): fitness / rmse partials of evaluate_registration against the whole memory
+__global__ __launch_bounds__(256) void ibl_evaluate_kernel(ibl_memgrid g, const float4* __restrict__ det, const EvalJob* __restrict__ jobs,
+                                                           float thr, float thr2, double* __restrict__ partial /* [J][BPJ][2] */) {
+    const int j = blockIdx.y;
+    const EvalJob job = jobs[j];
+    double cnt = 0, err2 = 0;
+    for (int i = job.begin + blockIdx.x * 256 + threadIdx.x; i < job.end; i += ICP_BPJ * 256) {
+        const float4 s4 = det[i];
+        double p[3];
+        xform_d(job.T, s4.x, s4.y, s4.z, p);
+        const float qx = (float)p[0], qy = (float)p[1], qz = (float)p[2];
+        float best = thr2;
+        bool found = false;
+        const int x0 = (int)floorf((qx - thr) * g.inv), x1 = (int)floorf((qx + thr) * g.inv);
+        const int y0 = (int)floorf((qy - thr) * g.inv), y1 = (int)floorf((qy + thr) * g.inv);
+        const int z0 = (int)floorf((qz - thr) * g.inv), z1 = (int)floorf((qz + thr) * g.inv);
+        for (int ix = x0; ix <= x1; ++ix)
+            for (int iy = y0; iy <= y1; ++iy)
+                for (int iz = z0; iz <= z1; ++iz) {
+                    const unsigned long long k = mg_key(ix, iy, iz);
+                    unsigned long long h = mg_hash(k) & g.hmask;
+                    int c = -1;
+                    while (true) {
+                        const unsigned long long tk = g.tkeys[h];
+                        if (tk == k) { c = g.tvals[h]; break; }
+                        if (tk == MG_EMPTY) break;
+                        h = (h + 1) & g.hmask;
+                    }
+                    if (c < 0) continue;
+                    const int b = g.ustart[c], e = g.ustart[c + 1];
+                    for (int t = b; t < e; ++t) {
+                        const float4 m = g.sorted[t];
+                        const float d2 = dist2f(qx, qy, qz, m.x, m.y, m.z);
+                        if (d2 < best) { best = d2; found = true; }
+                    }
+                }
+        if (found) { cnt += 1.0; err2 += (double)best; }
+    }
+    __shared__ double sh[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    cnt = wave_sum_d(cnt); err2 = wave_sum_d(err2);
+    if (lane == 0) { sh[0][wave] = cnt; sh[1][wave] = err2; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        partial[((int64_t)j * ICP_BPJ + blockIdx.x) * 2 + threadIdx.x] =
+            ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
+}
+
+extern "C" int ibl_evaluate_batch(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* det_pts4, const int32_t* job_begin,
+                                  const int32_t* job_end, const double* T_global, int n_jobs, double threshold, double* rmse_out,
+                                  double* fitness_out, void* stream) {
+    if (!ctx || !grid || !det_pts4 || !job_begin || !job_end || !T_global || !rmse_out || !fitness_out || n_jobs <= 0 || threshold <= 0)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_evaluate_batch: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ArenaMark mark(ctx);
+    const int J = n_jobs;
+    std::vector<EvalJob> jobs(J);
+    for (int j = 0; j < J; ++j) {
+        for (int t = 0; t < 12; ++t) jobs[j].T[t] = T_global[16 * j + t];
+        jobs[j].begin = job_begin[j]; jobs[j].end = job_end[j];
+        if (job_end[j] < job_begin[j]) return ibl_set_error(IBL_ERR_ARG, "ibl_evaluate_batch: bad point range");
+    }
+    EvalJob* d_jobs; double* partial;
+    IBL_ARENA(d_jobs, EvalJob, J);
+    IBL_ARENA(partial, double, (int64_t)J * ICP_BPJ * 2);
+    IBL_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(EvalJob) * J, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ibl_evaluate_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, *grid, reinterpret_cast<const float4*>(det_pts4), d_jobs,
+                       (float)threshold, (float)(threshold * threshold), partial);
+    IBL_LAUNCH_CHECK();
+    std::vector<double> h((size_t)J * ICP_BPJ * 2);
+    IBL_HIP_CHECK(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+    IBL_HIP_CHECK(hipStreamSynchronize(s));
+    for (int j = 0; j < J; ++j) {
+        double cnt = 0, err2 = 0;
+        for (int b = 0; b < ICP_BPJ; ++b) { cnt += h[((size_t)j * ICP_BPJ + b) * 2]; err2 += h[((size_t)j * ICP_BPJ + b) * 2 + 1]; }
+        const int ns = job_end[j] - job_begin[j];
+        fitness_out[j] = ns > 0 ? cnt / (double)ns : 0.0;
+        rmse_out[j] = cnt > 0 ? std::sqrt(err2 / cnt) : 0.0;
+    }
+    return IBL_OK;
+}

@@ -94,3 +94,77 @@ def normals_fpfh_batch(ctx: RegContext, batch: CloudBatch, radius_normal, max_nn
                                          fpfh.data_ptr() if fpfh is not None else None, _stream())
     _lib.check(st, "ibl_normals_fpfh_batch")
     return normals[:batch.n], (fpfh[:batch.n] if fpfh is not None else None)
+
+
+REG_HAVE_COLORS = 1
+REG_CENTER = 2
+
+
+def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_seg, job_tgt_seg, voxel_size,
+                   global_dist_factor=1.5, local_dist_factor=0.4, seed=0, job_id_base=0, ransac_max_iter=4000000,
+                   have_colors=True, center=True):
+    """Batched register_point_clouds (utils/fpfh_register.py:100-143).  job_*_seg: (J, <=3) int arrays of
+    pool segment ids (-1 padded).  Returns dict of host arrays: T (J,4,4), rmse, fitness, means (J,2,3),
+    T_ransac (J,4,4), ransac_stats (J,3)."""
+    def pad(a):
+        a = np.asarray(a, dtype=np.int32)
+        if a.ndim == 1:
+            a = a[:, None]
+        out = np.full((a.shape[0], 3), -1, dtype=np.int32)
+        out[:, :a.shape[1]] = a
+        return np.ascontiguousarray(out)
+
+    js, jt = pad(job_src_seg), pad(job_tgt_seg)
+    J = js.shape[0]
+    assert jt.shape[0] == J
+    T = np.zeros((J, 16), dtype=np.float64)
+    rmse = np.zeros(J, dtype=np.float64)
+    fit = np.zeros(J, dtype=np.float64)
+    means = np.zeros((J, 2, 3), dtype=np.float64)
+    Tr = np.zeros((J, 16), dtype=np.float64)
+    stats = np.zeros((J, 3), dtype=np.int64)
+    flags = (REG_HAVE_COLORS if have_colors else 0) | (REG_CENTER if center else 0)
+    st = _lib.lib.ibl_register_batch(ctx.handle, det.pts4.data_ptr(), det.seg_off.data_ptr(), det.seg_off_host.ctypes.data,
+                                     det.n_seg, mem.pts4.data_ptr(), mem.seg_off.data_ptr(), mem.seg_off_host.ctypes.data,
+                                     mem.n_seg, js.ctypes.data, jt.ctypes.data, J, float(voxel_size), float(global_dist_factor),
+                                     float(local_dist_factor), int(seed), int(job_id_base), int(ransac_max_iter), flags,
+                                     T.ctypes.data, rmse.ctypes.data, fit.ctypes.data, means.ctypes.data, Tr.ctypes.data,
+                                     stats.ctypes.data, _stream())
+    _lib.check(st, "ibl_register_batch")
+    return dict(T=T.reshape(J, 4, 4), rmse=rmse, fitness=fit, means=means, T_ransac=Tr.reshape(J, 4, 4), ransac_stats=stats)
+
+
+class MemGrid:
+    """Persistent spatial hash over all memory points (lives in the context arena)."""
+
+    def __init__(self, ctx: RegContext, mem_pts4: torch.Tensor, cell=0.04):
+        assert mem_pts4.is_cuda and mem_pts4.dtype == torch.float32 and mem_pts4.shape[1] == 4 and mem_pts4.is_contiguous()
+        self.ctx = ctx
+        self.cell = cell
+        self._h = C.c_void_p()
+        st = _lib.lib.ibl_memgrid_build(ctx.handle, mem_pts4.data_ptr(), mem_pts4.shape[0], float(cell), C.byref(self._h),
+                                        _stream())
+        _lib.check(st, "ibl_memgrid_build")
+
+    def close(self):
+        if self._h:
+            _lib.lib.ibl_memgrid_destroy(self._h)
+            self._h = C.c_void_p()
+
+    @property
+    def handle(self):
+        return self._h
+
+
+def evaluate_batch(ctx: RegContext, grid: MemGrid, det_pts4: torch.Tensor, job_begin, job_end, T_global, threshold=0.02):
+    """evaluate_transform (utils/fpfh_register.py:145-150) for J candidates; returns (rmse (J,), fitness (J,))."""
+    jb = np.ascontiguousarray(job_begin, dtype=np.int32)
+    je = np.ascontiguousarray(job_end, dtype=np.int32)
+    T = np.ascontiguousarray(T_global, dtype=np.float64).reshape(-1, 16)
+    J = len(jb)
+    rmse = np.zeros(J, dtype=np.float64)
+    fit = np.zeros(J, dtype=np.float64)
+    st = _lib.lib.ibl_evaluate_batch(ctx.handle, grid.handle, det_pts4.data_ptr(), jb.ctypes.data, je.ctypes.data, T.ctypes.data,
+                                     J, float(threshold), rmse.ctypes.data, fit.ctypes.data, _stream())
+    _lib.check(st, "ibl_evaluate_batch")
+    return rmse, fit
