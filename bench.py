@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- query-frames localised / second (embed + match + register) on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): DINOv2 ViT-B/14 crops (224^2, Q = 7 per frame), 1 000-instance
+memory (E = 4 stored embeddings each, 5 000-point coloured clouds), FPFH + RANSAC + coloured ICP on the
+5k-point clouds of every candidate assignment, whole-memory evaluation.  A "step" is one pass of the hot path
+(ObjectMemory.localise body, object_memory.py:911-1131) over one batch of --frames synthetic query frames whose
+crops and detected clouds are already resident in HBM.  Synthetic data and seeded random-init weights
+(no datasets / checkpoints offline).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: query frames are independent (tum_localisation_trial.py:215 has no cross-frame state), so each
+rank localises its own frames against a replicated memory -- no data-path collective, "scaling": "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def smooth_image(rng, size=224):
+    """a distinct low-frequency RGB pattern per instance (random-init ViTs barely separate white noise)"""
+    yy, xx = np.meshgrid(np.linspace(0, 1, size), np.linspace(0, 1, size), indexing="ij")
+    img = np.zeros((size, size, 3), dtype=np.float32)
+    for c in range(3):
+        acc = np.zeros((size, size), dtype=np.float32)
+        for _ in range(4):
+            fx, fy = rng.uniform(0.5, 6, size=2)
+            ph = rng.uniform(0, 2 * np.pi)
+            acc += rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * (fx * xx + fy * yy) + ph)
+        img[:, :, c] = acc
+    img = (img - img.min()) / (img.max() - img.min() + 1e-9)
+    return img
+
+
+def build_workload(args, rank, device):
+    import torch
+    from ibloc_amd import vit as V
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+    from ibloc_amd.registration import CloudBatch, RegContext
+    from ibloc_amd.synth import SynthWorld
+
+    t0 = time.time()
+    cfg = V.CONFIGS[args.model]
+    enc = V.VitEncoder(cfg, V.random_weights(cfg, 20), device=device)
+    world = SynthWorld(args.memory, pts_per_object=args.points, E=args.views, D=cfg.out_dim, seed=21)
+    rng = np.random.default_rng(21)
+    # per-instance base crop; memory views and query crops are noisy variants of it
+    base = np.stack([smooth_image(rng) for _ in range(args.memory)])              # (M, 224, 224, 3) in [0, 1]
+
+    def variants(ids, r):
+        out = np.empty((len(ids), 224, 224, 3), dtype=np.uint8)
+        for i, k in enumerate(ids):
+            v = base[k] + r.normal(0, 0.03, size=base[k].shape).astype(np.float32)
+            out[i] = np.clip(v * 255.0, 0, 255).astype(np.uint8)
+        return out
+
+    mem_emb = []
+    ids_all = np.repeat(np.arange(args.memory), args.views)
+    for i in range(0, len(ids_all), 256):
+        crops = torch.from_numpy(variants(ids_all[i:i + 256], rng)).to(device)
+        mem_emb.append(enc.embed(crops).cpu().numpy())
+    mem_emb = np.concatenate(mem_emb).reshape(args.memory, args.views, -1)
+    ctx = RegContext(int(args.arena_gb * (1 << 30)))
+    mem = MemoryShard(ctx, list(mem_emb), world.points, colors=world.colors, device=device)
+    eng = LocaliseEngine(mem, enc)
+    # query batches (distinct per step and per rank), device resident
+    batches = []
+    frng = np.random.default_rng(1000 + rank)
+    for step in range(args.warmup + args.steps):
+        clouds, ints, crop_ids, qs, poses, ids = [], [], [], [], [], []
+        for _ in range(args.frames):
+            f = world.make_frame(frng, q=args.q, pts_per_object=args.points)
+            for (p, c) in f["clouds"]:
+                clouds.append(p)
+                ints.append(intensity_from_colors(c))
+            crop_ids += f["ids"]
+            qs.append(len(f["ids"]))
+            poses.append(f["pose"])
+            ids.append(f["ids"])
+        det = CloudBatch.from_numpy(clouds, ints, device=device)
+        crops = torch.from_numpy(variants(crop_ids, frng)).to(device)
+        batches.append(dict(det=det, crops=crops, qs=qs, poses=poses, ids=ids))
+    if rank == 0:
+        print(f"[bench] setup {time.time() - t0:.1f}s: M={args.memory} E={args.views} pts={args.points} "
+              f"frames/step={args.frames} Q={args.q} model={args.model}", file=sys.stderr)
+    return eng, batches, world, mem_emb
+
+
+def run_step(eng, b, args, timings=None):
+    return eng.localise_batch(b["det"], b["qs"], crops=b["crops"], fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5,
+                              fpfh_local_dist_factor=1.5, seed=args.seed, timings=timings)
+
+
+def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
+    """The oracle (CPU restatement, `kind: port`) on a bounded sample: n_frames frames of the same workload.
+    Assignment uses the host search of the library (the reference's own O(M^3) volume cannot run at M = 1000)."""
+    import dataclasses
+
+    from ibloc_amd import vit as V
+    from ibloc_amd.assign import assign_batch
+    from ibloc_amd import preprocess as pp
+    from oracle import match_oracle as mo
+    from oracle import reg_oracle as ro
+    from oracle import vit_oracle as vo
+
+    cfg = V.CONFIGS[args.model]
+    w = V.random_weights(cfg, 20)
+    crops = batch["crops"].cpu().numpy()
+    det = batch["det"]
+    pts = det.pts4.cpu().numpy()
+    off = det.seg_off_host
+    mem_n = mo.normalize_rows(mem_emb.reshape(-1, mem_emb.shape[-1]))
+    emb_off = (np.arange(args.memory + 1) * args.views).astype(np.int32)
+    t0 = time.time()
+    row = 0
+    for f in range(n_frames):
+        q = batch["qs"][f]
+        e = vo.embed_crops(w, cfg, pp.RECIPES[cfg.recipe], list(crops[row:row + q]))
+        sims = mo.closest_similarity(mo.normalize_rows(e), mem_n, emb_off)
+        aug = np.ones((1, 7, args.memory + 1), dtype=np.float16)
+        aug[0, :q, :-1] = sims
+        assns = assign_batch(aug, [q], 4, 1)[0]
+        cleaned, cint = [], []
+        for d in range(q):
+            p = pts[off[row + d]:off[row + d + 1]]
+            k = ro.radius_outlier(p[:, :3], 0.05, 8)
+            cleaned.append(p[k, :3])
+            cint.append(np.repeat(p[k, 3:4], 3, axis=1))
+        ro.localise_from_assignments(cleaned, cint, world.points, world.colors, assns, 0.05, 1.5, 1.5, seed=args.seed)
+        row += q
+    dt = time.time() - t0
+    return n_frames / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=16, help="query frames per step and per GPU")
+    ap.add_argument("--memory", type=int, default=1000)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--q", type=int, default=7)
+    ap.add_argument("--model", default="dinov2_vitb14")
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--arena-gb", type=float, default=24.0)
+    ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--profile-kernel", default="", help="(internal) name of the kernel the roofline is reported for")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    eng, batches, world, mem_emb = build_workload(args, rank, device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run_step(eng, batches[i], args)
+    barrier()
+    from ibloc_amd import prof
+    prof.reset()
+    timings = {}
+    t0 = time.perf_counter()
+    ok = 0
+    for i in range(args.steps):
+        res = run_step(eng, batches[args.warmup + i], args, timings=timings)
+        b = batches[args.warmup + i]
+        for f, r in enumerate(res):
+            P = b["poses"][f]
+            ok += int(np.linalg.norm(r.pose_corrected[:3] - P[:3, 3]) < 0.6)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_frames = args.frames * args.steps * world_size
+    value = total_frames / dt
+
+    if rank == 0:
+        roof = prof.roofline()
+        cpu = None
+        if args.cpu_frames > 0:
+            v, cdt = cpu_baseline(args, world, mem_emb, batches[args.warmup], args.cpu_frames)
+            cpu = {"value": v, "unit": "query-frames/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                   "kind": "port", "sample": f"{args.cpu_frames} frame(s) of the same workload, {cdt:.1f} s: torch-cpu fp32 ViT + "
+                   "C oracle (match, FPFH, RANSAC, coloured ICP, evaluate; OpenMP) + host assignment search"}
+        out = {
+            "metric": "query-frames localized/sec (embed+match+register)",
+            "value": value,
+            "unit": "query-frames/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16 (ViT MFMA) / f32+f64 (match, registration)",
+            "data": "synthetic",
+            "config": {"workload": "C2: DINOv2 ViT-B/14 crops 224^2 (Q=7), 1k-instance memory (E=4), FPFH+RANSAC+coloured ICP "
+                       "on 5k-pt clouds, whole-memory evaluate", "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
+                       "points_per_object": args.points, "model": args.model, "parallelism": f"frames-dp{world_size}"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "stage_ms_per_step": {k: v / args.steps for k, v in timings.items() if isinstance(v, float)},
+            "localised_within_0.6m": ok / max(1, args.frames * args.steps),
+        }
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

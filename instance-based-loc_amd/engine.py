@@ -1,0 +1,174 @@
+"""Batched localisation engine: embed -> match -> assign -> register -> evaluate -> pose for many query
+frames at once.  This is the MI355X restatement of the body of ObjectMemory.localise()
+(/root/reference/object_memory/object_memory.py:911-1131); the per-frame facade with the reference's
+signature lives in object_memory/object_memory.py.
+
+Everything numerical runs in libibloc_hip.so; torch is used for device memory, stream handling and
+order-preserving boolean compaction only.
+"""
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+from . import match
+from .assign import assign_batch
+from .registration import CloudBatch, MemGrid, RegContext, evaluate_batch, radius_outlier_batch, register_batch
+
+
+def intensity_from_colors(colors) -> np.ndarray:
+    """(r + g + b) / 3 in float64, rounded to fp32 -- the only colour quantity coloured ICP reads."""
+    c = np.asarray(colors, dtype=np.float64)
+    return ((c[:, 0] + c[:, 1] + c[:, 2]) / 3.0).astype(np.float32)
+
+
+class MemoryShard:
+    """Device-resident object memory: all stored embeddings (L2-normalised once),
+    per-instance point clouds (x, y, z, intensity) and the spatial hash used by evaluate_transform."""
+
+    def __init__(self, ctx: RegContext, embeddings, clouds, colors=None, intensities=None, eval_threshold=0.02, device="cuda"):
+        self.ctx = ctx
+        self.device = torch.device(device)
+        counts = [len(e) for e in embeddings]
+        self.M = len(counts)
+        self.emb_offsets_host = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        raw = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(e, dtype=np.float32) for e in embeddings])))
+        self.mem_emb = match.normalize_rows(raw.to(self.device))          # object_memory.py:922
+        self.emb_offsets = torch.from_numpy(self.emb_offsets_host).to(self.device)
+        if intensities is None:
+            intensities = [intensity_from_colors(c) for c in colors] if colors is not None else None
+        self.clouds = CloudBatch.from_numpy(clouds, intensities, device=device)
+        self.eval_threshold = eval_threshold
+        self.grid = MemGrid(ctx, self.clouds.pts4, cell=2 * eval_threshold)
+
+
+@dataclass
+class FrameResult:
+    pose: np.ndarray                      # reference-faithful [x, y, z, qx, qy, qz, qw] (object_memory.py:1124-1131)
+    pose_corrected: np.ndarray            # same, with the best assignment's own means (App. B item 4 fixed)
+    assignments: list = field(default_factory=list)
+    records: list = field(default_factory=list)
+    best: int = -1
+
+
+class LocaliseEngine:
+    def __init__(self, memory: MemoryShard, encoder=None, assign_threads=0):
+        self.memory = memory
+        self.encoder = encoder
+        self.ctx = memory.ctx
+        self.assign_threads = assign_threads or min(os.cpu_count() or 1, 16)
+
+    def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
+                       fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, outlier_radius=0.05, outlier_nb_points=8,
+                       seed=0, job_id_base=0, ransac_max_iter=4000000, num_per_length=4, eval_threshold=None, timings=None):
+        """det: detected clouds of all frames (segments in frame order, <= 7 per frame); crops: uint8 tensor
+        (sum Q, H, W, 3) or list of arrays, or det_emb: (sum Q, D) precomputed embeddings."""
+        mem = self.memory
+        q_per_frame = np.asarray(q_per_frame, dtype=np.int32)
+        F = len(q_per_frame)
+        row0 = np.concatenate([[0], np.cumsum(q_per_frame)]).astype(np.int64)
+        assert det.n_seg == int(row0[-1])
+        ev = []
+
+        def tick(name):
+            if timings is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+
+        tick("start")
+        # ---- embed + match (GPU) -------------------------------------------------------------------
+        if det_emb is None:
+            if self.encoder is None:
+                raise ValueError("no encoder: pass det_emb")
+            det_emb = self.encoder.embed(crops)
+        else:
+            det_emb = torch.as_tensor(det_emb, dtype=torch.float32, device=mem.device).contiguous()
+        tick("embed")
+        # Q > M truncates the detections that are matched (object_memory.py:918-920)
+        detn = match.normalize_rows(det_emb)                                        # :924
+        _, aug = match.closest_similarity(detn, mem.mem_emb, mem.emb_offsets, want_sims=False, want_aug=True)   # :933-936, sim_volume :13-18
+        tick("match")
+        # ---- clean the detected clouds (:992-998) ---------------------------------------------------
+        keep = radius_outlier_batch(self.ctx, det, outlier_radius, outlier_nb_points)
+        keepb = keep.bool()
+        csum = torch.cumsum(keep.to(torch.int32), 0)
+        csum0 = torch.cat([torch.zeros(1, dtype=torch.int32, device=csum.device), csum])
+        new_off = csum0[det.seg_off.long()]
+        clean_pts = det.pts4[keepb].contiguous()
+        tick("outlier")
+        # ---- one host round trip: fp16 similarity rows + cleaned sizes ------------------------------
+        aug_h = aug.cpu().numpy()
+        new_off_h = new_off.cpu().numpy().astype(np.int32)
+        clean = CloudBatch(clean_pts, new_off_h)
+        tick("d2h")
+        # ---- assign (host, exact similarity-volume search; :974-982) --------------------------------
+        M = mem.M
+        aug_f = np.ones((F, 7, M + 1), dtype=np.float16)
+        q_emb = np.minimum(q_per_frame, M)
+        for f in range(F):
+            if q_per_frame[f] > 7:
+                raise ValueError("more than 7 detections in a frame: select the 7 largest first (object_memory.py:900-908)")
+            if q_emb[f] < min(q_per_frame[f], 3):
+                raise AssertionError("fewer memory objects than the sub-volume dimension (reference asserts at similarity_volume.py:112)")
+            aug_f[f, :q_emb[f]] = aug_h[row0[f]:row0[f] + q_emb[f]]
+        assns = assign_batch(aug_f, q_emb, num_per_length, self.assign_threads)
+        if timings is not None:
+            timings.setdefault("assign_host_s", 0.0)
+        tick("assign")
+        # ---- registration jobs (:1020-1106) ----------------------------------------------------------
+        job_frame, job_src, job_tgt = [], [], []
+        for f in range(F):
+            for a in assns[f]:
+                job_frame.append(f)
+                job_src.append([int(row0[f]) + d for d, m in a] + [-1] * (3 - len(a)))
+                job_tgt.append([m for d, m in a] + [-1] * (3 - len(a)))
+        results = [FrameResult(np.array([0., 0., 0., 0., 0., 0., 1.]), np.array([0., 0., 0., 0., 0., 0., 1.])) for _ in range(F)]
+        if not job_frame:
+            return results
+        J = len(job_frame)
+        reg = register_batch(self.ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
+                             fpfh_local_dist_factor, seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter,
+                             have_colors=True, center=True)
+        tick("register")
+        # global-frame transforms (:1096-1101)
+        T = reg["T"]
+        G = T.copy()
+        for j in range(J):
+            R = T[j, :3, :3]
+            G[j, :3, 3] = T[j, :3, 3] + reg["means"][j, 1] - R @ reg["means"][j, 0]
+        jb = [int(new_off_h[row0[f]]) for f in job_frame]
+        je = [int(new_off_h[row0[f + 1]]) for f in job_frame]
+        thr = eval_threshold if eval_threshold is not None else mem.eval_threshold
+        full_rmse, full_fit = evaluate_batch(self.ctx, mem.grid, clean.pts4, jb, je, G, thr)     # :1104
+        tick("evaluate")
+        # ---- selection + pose (:1111-1131) -----------------------------------------------------------
+        j = 0
+        for f in range(F):
+            n_a = len(assns[f])
+            if n_a == 0:
+                continue
+            recs = []
+            for k in range(n_a):
+                recs.append(dict(assn=assns[f][k], T=T[j + k], rmse=reg["rmse"][j + k], fitness=reg["fitness"][j + k],
+                                 full_rmse=full_rmse[j + k], full_fitness=full_fit[j + k], T_global=G[j + k],
+                                 detected_mean=reg["means"][j + k, 0], memory_mean=reg["means"][j + k, 1],
+                                 ransac_stats=reg["ransac_stats"][j + k]))
+            order = sorted(range(n_a), key=lambda k: recs[k]["full_fitness"], reverse=True)   # stable, like sorted() at :1111
+            best = order[0]
+            R = recs[best]["T"][:3, :3]
+            t = recs[best]["T"][:3, 3]
+            q = Rotation.from_matrix(R).as_quat()
+            last = recs[-1]
+            t_ref = t + last["memory_mean"] - R @ last["detected_mean"]           # stale means of the LAST assignment (:1127)
+            t_fix = t + recs[best]["memory_mean"] - R @ recs[best]["detected_mean"]
+            results[f] = FrameResult(np.concatenate((t_ref, q)), np.concatenate((t_fix, q)), assns[f], recs, best)
+            j += n_a
+        tick("select")
+        if timings is not None:
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+                timings[n1] = timings.get(n1, 0.0) + e0.elapsed_time(e1)
+        return results

@@ -1,0 +1,76 @@
+"""-m gpu: the batched localisation engine end to end (match -> assign -> register -> evaluate -> pose)
+against the oracle transcript of object_memory.py:911-1131 and against the synthetic ground truth."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial.transform import Rotation
+
+from ibloc_amd.synth import SynthWorld
+from oracle import match_oracle as mo
+from oracle import reg_oracle as ro
+from oracle import simvolume_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def rot_deg(Ra, Rb):
+    return float(np.degrees(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1))))
+
+
+def test_localise_batch_matches_oracle_and_ground_truth():
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+    from ibloc_amd.registration import CloudBatch, RegContext
+    ctx = RegContext(6 << 30)
+    w = SynthWorld(9, pts_per_object=3000, E=3, D=64, seed=31)
+    rng = np.random.default_rng(32)
+    frames = [w.make_frame(rng, q=3, pts_per_object=3000, anchor=4), w.make_frame(rng, q=2, pts_per_object=3000, anchor=0)]
+    mem = MemoryShard(ctx, list(w.embeddings), w.points, colors=w.colors)
+    eng = LocaliseEngine(mem)
+    clouds, ints, embs, qs = [], [], [], []
+    for f in frames:
+        for (p, c) in f["clouds"]:
+            clouds.append(p)
+            ints.append(intensity_from_colors(c))
+        embs.append(f["det_emb"])
+        qs.append(len(f["clouds"]))
+    det = CloudBatch.from_numpy(clouds, ints)
+    res = eng.localise_batch(det, qs, det_emb=np.concatenate(embs), fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5,
+                             fpfh_local_dist_factor=1.5, seed=5, job_id_base=0)
+    # ---- oracle transcript ---------------------------------------------------------------------
+    off = np.concatenate([[0], np.cumsum([len(e) for e in w.embeddings])]).astype(np.int32)
+    mem_n = mo.normalize_rows(np.concatenate(list(w.embeddings)))
+    job = 0
+    n_correct = 0
+    for fi, f in enumerate(frames):
+        sims = mo.closest_similarity(mo.normalize_rows(f["det_emb"]), mem_n, off)
+        assns = so.simvolume_assignments(sims, 4)
+        assert res[fi].assignments == assns                                    # bit-exact indices
+        cleaned, ccols = [], []
+        for (p, c) in f["clouds"]:
+            k = ro.radius_outlier(p.astype(np.float32), 0.05, 8)
+            cleaned.append(p[k])
+            ccols.append(c[k])
+        pose, recs, best = ro.localise_from_assignments(cleaned, ccols, w.points, w.colors, assns, 0.05, 1.5, 1.5, seed=5,
+                                                        job_base=job, stale_means=True)
+        job += len(assns)
+        for k, (a, b) in enumerate(zip(res[fi].records, recs)):
+            assert abs(a["full_fitness"] - b["full_fitness"]) < 5e-3, (fi, k, a["full_fitness"], b["full_fitness"])
+        assert res[fi].best == best
+        assert np.linalg.norm(res[fi].pose[:3] - pose[:3]) <= 0.01                # 1 cm / 0.5 deg vs the oracle
+        assert rot_deg(Rotation.from_quat(res[fi].pose[3:]).as_matrix(), Rotation.from_quat(pose[3:]).as_matrix()) <= 0.5
+        P = f["pose"]
+        t_err = np.linalg.norm(res[fi].pose_corrected[:3] - P[:3, 3])
+        r_err = np.radians(rot_deg(Rotation.from_quat(res[fi].pose_corrected[3:]).as_matrix(), P[:3, :3]))
+        best_assn = res[fi].assignments[best]
+        correct = all(f["ids"][d] == m for d, m in best_assn)
+        print("frame", fi, "ids", f["ids"], "assns", assns, "best", best, "correct", correct, "t err", t_err, "r err", r_err,
+              "full fitness", [round(r["full_fitness"], 4) for r in res[fi].records])
+        # success (reference thresholds, tum_localisation_trial.py:274) at least as often as the oracle
+        pose_o, _, _ = ro.localise_from_assignments(cleaned, ccols, w.points, w.colors, assns, 0.05, 1.5, 1.5, seed=5,
+                                                    job_base=job - len(assns), stale_means=False)
+        t_o = np.linalg.norm(pose_o[:3] - P[:3, 3])
+        r_o = np.radians(rot_deg(Rotation.from_quat(pose_o[3:]).as_matrix(), P[:3, :3]))
+        assert (t_err < 0.6 and r_err < 0.3) == (t_o < 0.6 and r_o < 0.3)
+        n_correct += int(t_err < 0.6 and r_err < 0.3)
+    assert n_correct >= 1
+    ctx.close()
