@@ -27,7 +27,6 @@ int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals
 int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
                           int max_nn, float4* grad, int* status, hipStream_t s);
 
-#define HB 4096          // RANSAC hypotheses per job per round
 #define ICP_BPJ 32       // blocks per job in the ICP / evaluation reductions
 #define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
 
@@ -167,11 +166,24 @@ __global__ __launch_bounds__(256) void ibl_mutual_kernel(const int* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // RANSAC
+//
+// Rounds of up to RANSAC_MAX_ROUND hypotheses per job.  Per round:
+//   flag    thread per hypothesis: Philox draw, edge-length check, 3-point Kabsch, distance check -> 1 byte,
+//           plus the count of survivors of every 256-hypothesis block
+//   scan    exclusive sum of the block counts (hipcub) -> ordered offsets
+//   scatter ordered list of surviving (job, hypothesis) ids
+//   score   one wavefront per survivor: recompute its transform, validate it on the correspondence set
+//   fold    one wavefront per job: walk the survivors in hypothesis order and reproduce the sequential
+//           "better result -> tighten est_k" bookkeeping of the reference loop exactly
+// Correspondences are packed as (source xyz, target xyz) pairs so that a draw costs two 16-byte loads.
 // ------------------------------------------------------------------------------------------------
+#define RANSAC_MAX_ROUND 262144
+#define RANSAC_FIRST_ROUND 4096
+
 struct RansacState {
     double best_T[16];
     double best_fit, best_rmse;
-    long long est_k, next_i, walked, validated;
+    long long est_k, next_i, walked, validated, last_update;
     int best_inl;
     int done;
 };
@@ -182,86 +194,129 @@ __global__ void ibl_ransac_init_kernel(RansacState* __restrict__ st, const int* 
     if (j >= J) return;
     RansacState s;
     for (int i = 0; i < 16; ++i) s.best_T[i] = (i % 5) == 0 ? 1.0 : 0.0;
-    s.best_fit = 0; s.best_rmse = 0; s.est_k = max_iter; s.next_i = 0; s.walked = 0; s.validated = 0; s.best_inl = 0;
+    s.best_fit = 0; s.best_rmse = 0; s.est_k = max_iter; s.next_i = 0; s.walked = 0; s.validated = 0; s.best_inl = 0; s.last_update = -1;
     s.done = (n_corr[j] < 3 || max_dist <= 0) ? 1 : 0;
     st[j] = s;
 }
 
-// thread per (job, slot): draw, edge-length check, Kabsch, distance check
-__global__ __launch_bounds__(256) void ibl_ransac_hyp_kernel(const RansacState* __restrict__ st, const float4* __restrict__ pts,
-                                                             const int* __restrict__ job_off, int J, const int2* __restrict__ corr,
-                                                             const int* __restrict__ n_corr, double max_dist, double edge_sim,
-                                                             unsigned seed_lo, unsigned seed_hi, unsigned job_id_base,
-                                                             double* __restrict__ hyp_T /* [J][HB][12] */,
-                                                             unsigned char* __restrict__ hyp_valid /* [J][HB] */) {
+// packed correspondences: cp[2c] = source point, cp[2c + 1] = target point
+__global__ __launch_bounds__(256) void ibl_pack_corr_kernel(const float4* __restrict__ pts, const int* __restrict__ job_off, int J,
+                                                            const int2* __restrict__ corr, const int* __restrict__ n_corr,
+                                                            float4* __restrict__ cp) {
     const int j = blockIdx.y;
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    const RansacState& S = st[j];
-    unsigned char ok = 0;
-    const long long i = S.next_i + slot;
-    if (!S.done && i < S.est_k) {
-        const int nc = n_corr[j];
-        const int sb = job_off[j], tb = job_off[J + j];
-        unsigned r[4];
-        philox4x32((unsigned)i, job_id_base + (unsigned)j, (unsigned)((unsigned long long)i >> 32), 0u, seed_lo, seed_hi, r);
-        double s[9], d[9];
-        for (int t = 0; t < 3; ++t) {
-            const int pick = (int)(((unsigned long long)r[t] * (unsigned long long)nc) >> 32);
-            const int2 c = corr[sb + pick];
-            const float4 ps = pts[sb + c.x], pd = pts[tb + c.y];
-            s[3 * t] = ps.x; s[3 * t + 1] = ps.y; s[3 * t + 2] = ps.z;
-            d[3 * t] = pd.x; d[3 * t + 1] = pd.y; d[3 * t + 2] = pd.z;
-        }
-        ok = 1;
-        for (int a = 0; a < 3 && ok; ++a)
-            for (int b = a + 1; b < 3; ++b) {
-                const double ds = sqrt((s[3 * a] - s[3 * b]) * (s[3 * a] - s[3 * b]) + (s[3 * a + 1] - s[3 * b + 1]) * (s[3 * a + 1] - s[3 * b + 1]) +
-                                       (s[3 * a + 2] - s[3 * b + 2]) * (s[3 * a + 2] - s[3 * b + 2]));
-                const double dt = sqrt((d[3 * a] - d[3 * b]) * (d[3 * a] - d[3 * b]) + (d[3 * a + 1] - d[3 * b + 1]) * (d[3 * a + 1] - d[3 * b + 1]) +
-                                       (d[3 * a + 2] - d[3 * b + 2]) * (d[3 * a + 2] - d[3 * b + 2]));
-                if (ds < dt * edge_sim || dt < ds * edge_sim) { ok = 0; break; }
-            }
-        if (ok) {
-            double sm[3] = {0, 0, 0}, dm[3] = {0, 0, 0};
-            for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) { sm[a] += s[3 * t + a]; dm[a] += d[3 * t + a]; }
-            for (int a = 0; a < 3; ++a) { sm[a] /= 3; dm[a] /= 3; }
-            double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-            for (int t = 0; t < 3; ++t)
-                for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) H[rr][cc] += (d[3 * t + rr] - dm[rr]) * (s[3 * t + cc] - sm[cc]);
-            double T[16];
-            kabsch_from_moments(sm, dm, H, T);
-            for (int t = 0; t < 3 && ok; ++t) {
-                double p[3];
-                xform_d(T, s[3 * t], s[3 * t + 1], s[3 * t + 2], p);
-                const double dx = p[0] - d[3 * t], dy = p[1] - d[3 * t + 1], dz = p[2] - d[3 * t + 2];
-                if (sqrt(dx * dx + dy * dy + dz * dz) > max_dist) ok = 0;
-            }
-            if (ok) {
-                double* o = hyp_T + ((int64_t)j * HB + slot) * 12;
-                for (int t = 0; t < 12; ++t) o[t] = T[t];
-            }
-        }
+    const int sb = job_off[j], tb = job_off[J + j], nc = n_corr[j];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nc; c += gridDim.x * 256) {
+        const int2 cc = corr[sb + c];
+        cp[2 * (int64_t)(sb + c)] = pts[sb + cc.x];
+        cp[2 * (int64_t)(sb + c) + 1] = pts[tb + cc.y];
     }
-    hyp_valid[(int64_t)j * HB + slot] = ok;
 }
 
-// wave per (job, slot): validation on the correspondence set
-__global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const float4* __restrict__ pts, const int* __restrict__ job_off, int J,
-                                                               const int2* __restrict__ corr, const int* __restrict__ n_corr, double max_dist,
-                                                               const double* __restrict__ hyp_T, const unsigned char* __restrict__ hyp_valid,
-                                                               int* __restrict__ hyp_inl, double* __restrict__ hyp_err2) {
+// hypothesis -> transform; returns false when a checker rejects it
+__device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned seed_lo, unsigned seed_hi, const float4* __restrict__ cp,
+                                         int nc, double max_dist, double edge_sim, double* T) {
+    unsigned r[4];
+    philox4x32((unsigned)i, job_id, (unsigned)((unsigned long long)i >> 32), 0u, seed_lo, seed_hi, r);
+    double s[9], d[9];
+    for (int t = 0; t < 3; ++t) {
+        const int pick = (int)(((unsigned long long)r[t] * (unsigned long long)nc) >> 32);
+        const float4 ps = cp[2 * pick], pd = cp[2 * pick + 1];
+        s[3 * t] = ps.x; s[3 * t + 1] = ps.y; s[3 * t + 2] = ps.z;
+        d[3 * t] = pd.x; d[3 * t + 1] = pd.y; d[3 * t + 2] = pd.z;
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b) {
+            const double ds = sqrt((s[3 * a] - s[3 * b]) * (s[3 * a] - s[3 * b]) + (s[3 * a + 1] - s[3 * b + 1]) * (s[3 * a + 1] - s[3 * b + 1]) +
+                                   (s[3 * a + 2] - s[3 * b + 2]) * (s[3 * a + 2] - s[3 * b + 2]));
+            const double dt = sqrt((d[3 * a] - d[3 * b]) * (d[3 * a] - d[3 * b]) + (d[3 * a + 1] - d[3 * b + 1]) * (d[3 * a + 1] - d[3 * b + 1]) +
+                                   (d[3 * a + 2] - d[3 * b + 2]) * (d[3 * a + 2] - d[3 * b + 2]));
+            if (ds < dt * edge_sim || dt < ds * edge_sim) return false;
+        }
+    double sm[3] = {0, 0, 0}, dm[3] = {0, 0, 0};
+    for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) { sm[a] += s[3 * t + a]; dm[a] += d[3 * t + a]; }
+    for (int a = 0; a < 3; ++a) { sm[a] /= 3; dm[a] /= 3; }
+    double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int t = 0; t < 3; ++t)
+        for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) H[rr][cc] += (d[3 * t + rr] - dm[rr]) * (s[3 * t + cc] - sm[cc]);
+    kabsch_from_moments(sm, dm, H, T);
+    for (int t = 0; t < 3; ++t) {
+        double p[3];
+        xform_d(T, s[3 * t], s[3 * t + 1], s[3 * t + 2], p);
+        const double dx = p[0] - d[3 * t], dy = p[1] - d[3 * t + 1], dz = p[2] - d[3 * t + 2];
+        if (sqrt(dx * dx + dy * dy + dz * dz) > max_dist) return false;
+    }
+    return true;
+}
+
+// grid (round / 256, J)
+__global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
+                                                              const int* __restrict__ job_off, const int* __restrict__ n_corr,
+                                                              long long max_iter, double max_dist, double edge_sim, unsigned seed_lo,
+                                                              unsigned seed_hi, unsigned job_id_base, int round_size,
+                                                              unsigned char* __restrict__ flags /* [J][round] */,
+                                                              int* __restrict__ blk_cnt /* [J][round/256] */) {
     const int j = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nblk = round_size / 256;
+    const RansacState& S = st[j];
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const long long i = S.next_i + slot;
+    bool ok = false;
+    if (!S.done && i < S.est_k && i < max_iter) {
+        double T[16];
+        ok = ransac_hypothesis(i, job_id_base + (unsigned)j, seed_lo, seed_hi, cp + 2 * (int64_t)job_off[j], n_corr[j], max_dist, edge_sim, T);
+    }
+    flags[(int64_t)j * round_size + slot] = ok ? 1 : 0;
+    __shared__ int wc[4];
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[j * nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned char* __restrict__ flags, const int* __restrict__ blk_off,
+                                                                 int round_size, int* __restrict__ list /* slot ids, ordered */) {
+    const int j = blockIdx.y;
+    const int nblk = round_size / 256;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = flags[(int64_t)j * round_size + slot] != 0;
+    __shared__ int wc[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wc[wave] = __popcll(m);
+    __syncthreads();
+    if (ok) {
+        int pre = blk_off[j * nblk + blockIdx.x];
+        for (int w = 0; w < wave; ++w) pre += wc[w];
+        list[pre + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+    }
+}
+
+// wave per survivor e in [0, total): job = the job whose offset range contains e
+__global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
+                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr, int J,
+                                                               double max_dist, double edge_sim, unsigned seed_lo, unsigned seed_hi,
+                                                               unsigned job_id_base, int round_size, const int* __restrict__ blk_off,
+                                                               const int* __restrict__ list, int total, int* __restrict__ e_inl,
+                                                               double* __restrict__ e_err2, double* __restrict__ e_T) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= total) return;
     const int lane = threadIdx.x & 63;
-    if (!hyp_valid[(int64_t)j * HB + slot]) return;
-    double T[12];
-    for (int t = 0; t < 12; ++t) T[t] = hyp_T[((int64_t)j * HB + slot) * 12 + t];
-    const int nc = n_corr[j], sb = job_off[j], tb = job_off[J + j];
+    const int nblk = round_size / 256;
+    int lo = 0, hi = J;                       // largest j with blk_off[j * nblk] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk_off[mid * nblk] <= e) lo = mid; else hi = mid;
+    }
+    const int j = lo;
+    const long long i = st[j].next_i + list[e];
+    const float4* c = cp + 2 * (int64_t)job_off[j];
+    const int nc = n_corr[j];
+    double T[16];
+    ransac_hypothesis(i, job_id_base + (unsigned)j, seed_lo, seed_hi, c, nc, max_dist, edge_sim, T);
     int inl = 0;
     double err2 = 0;
-    for (int c = lane; c < nc; c += 64) {
-        const int2 cc = corr[sb + c];
-        const float4 ps = pts[sb + cc.x], q = pts[tb + cc.y];
+    for (int k = lane; k < nc; k += 64) {
+        const float4 ps = c[2 * k], q = c[2 * k + 1];
         double p[3];
         xform_d(T, ps.x, ps.y, ps.z, p);
         const double dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
@@ -270,41 +325,72 @@ __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const float4* __r
     }
     inl = wave_sum_i(inl);
     err2 = wave_sum_d(err2);
-    if (lane == 0) { hyp_inl[(int64_t)j * HB + slot] = inl; hyp_err2[(int64_t)j * HB + slot] = err2; }
+    if (lane == 0) { e_inl[e] = inl; e_err2[e] = err2; }
+    if (lane < 12) e_T[(int64_t)e * 12 + lane] = T[lane];
 }
 
-// thread per job: fold the round in hypothesis order
-__global__ void ibl_ransac_scan_kernel(RansacState* __restrict__ st, int J, const int* __restrict__ n_corr, long long max_iter,
-                                       double confidence, const double* __restrict__ hyp_T, const unsigned char* __restrict__ hyp_valid,
-                                       const int* __restrict__ hyp_inl, const double* __restrict__ hyp_err2, int* __restrict__ n_active) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= J) return;
+// wave per job: fold the round's survivors in hypothesis order
+__global__ __launch_bounds__(64) void ibl_ransac_fold_kernel(RansacState* __restrict__ st, int J, const int* __restrict__ n_corr,
+                                                             long long max_iter, double confidence, int round_size,
+                                                             const int* __restrict__ blk_off, const int* __restrict__ list,
+                                                             const int* __restrict__ e_inl, const double* __restrict__ e_err2,
+                                                             const double* __restrict__ e_T, int total, int* __restrict__ n_active) {
+    const int j = blockIdx.x;
+    const int lane = threadIdx.x;
     RansacState S = st[j];
     if (S.done) return;
+    const int nblk = round_size / 256;
+    const int b = blk_off[j * nblk], e = (j + 1 < J) ? blk_off[(j + 1) * nblk] : total;
     const int nc = n_corr[j];
-    long long i = S.next_i;
-    const long long end = S.next_i + HB;
-    for (; i < end; ++i) {
-        if (i >= max_iter || i >= S.est_k) { S.done = 1; break; }
-        const int slot = (int)(i - S.next_i);
-        if (!hyp_valid[(int64_t)j * HB + slot]) continue;
-        S.validated++;
-        const int inl = hyp_inl[(int64_t)j * HB + slot];
-        const double err2 = hyp_err2[(int64_t)j * HB + slot];
-        const double fit = (double)inl / (double)nc, rmse = inl ? sqrt(err2 / inl) : 0.0;
-        if (inl > 0 && (fit > S.best_fit || (fit == S.best_fit && rmse < S.best_rmse))) {
-            S.best_fit = fit; S.best_rmse = rmse; S.best_inl = inl;
-            const double* T = hyp_T + ((int64_t)j * HB + slot) * 12;
-            for (int t = 0; t < 12; ++t) S.best_T[t] = T[t];
-            const double ek = log(1.0 - confidence) / log(1.0 - pow(fit, 3.0));
-            if (ek < (double)S.est_k) S.est_k = (long long)ceil(ek);
+    bool stop = false;
+    long long n_before_stop = 0;          // survivors with index < the stopping index in this round
+    for (int c0 = b; c0 < e && !stop; c0 += 64) {
+        const int k = c0 + lane;
+        const bool v = k < e;
+        const int inl = v ? e_inl[k] : -1;
+        const long long idx = v ? S.next_i + list[k] : 0x7FFFFFFFFFFFFFFFll;
+        unsigned long long cand = __ballot(v && inl > 0 && inl >= S.best_inl);
+        while (cand) {
+            const int t = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const long long ci = __shfl(idx, t, 64);
+            if (ci >= S.est_k) { stop = true; break; }
+            const int cinl = __shfl(inl, t, 64);
+            if (cinl < S.best_inl) continue;                    // best_inl may have grown inside this chunk
+            const double cerr2 = e_err2[c0 + t];
+            const double fit = (double)cinl / (double)nc, rmse = sqrt(cerr2 / cinl);
+            if (fit > S.best_fit || (fit == S.best_fit && rmse < S.best_rmse)) {
+                S.best_fit = fit; S.best_rmse = rmse; S.best_inl = cinl; S.last_update = ci;
+                if (lane < 12) S.best_T[lane] = e_T[(int64_t)(c0 + t) * 12 + lane];
+                const double ek = log(1.0 - confidence) / log(1.0 - pow(fit, 3.0));
+                if (ek < (double)S.est_k) S.est_k = (long long)ceil(ek);
+            }
         }
+        // survivors of this chunk that the reference loop walks: it stands at max(last update + 1, est_k)
+        long long lim = S.last_update + 1 > S.est_k ? S.last_update + 1 : S.est_k;
+        if (lim > max_iter) lim = max_iter;
+        n_before_stop += __popcll(__ballot(v && idx < lim));
+        if (!stop) { const unsigned long long beyond = __ballot(v && idx >= lim); if (beyond) stop = true; }
     }
-    S.walked = i;                 // hypotheses walked so far (== the loop index at which the reference loop stands)
+    const long long end = S.next_i + round_size;
+    const long long lim = S.est_k < max_iter ? S.est_k : max_iter;
+    S.validated += n_before_stop;
     S.next_i = end;
-    if (!S.done && (end >= max_iter || end >= S.est_k)) S.done = 1;
-    st[j] = S;
-    if (!S.done) atomicAdd(n_active, 1);
+    if (stop || end >= lim) {
+        S.done = 1;
+        long long w = S.last_update + 1 > lim ? S.last_update + 1 : lim;   // the reference loop stands at max(i0 + 1, est_k)
+        if (w > max_iter) w = max_iter;
+        S.walked = w;
+    } else {
+        S.walked = end;
+    }
+    // best_T lanes 0..11 were written by the owning lanes: gather them to lane 0's copy
+    double bt = lane < 12 ? S.best_T[lane] : 0.0;
+    for (int t = 0; t < 12; ++t) { const double v = __shfl(bt, t, 64); if (lane == 0) S.best_T[t] = v; }
+    if (lane == 0) {
+        st[j] = S;
+        if (!S.done) atomicAdd(n_active, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -593,33 +679,59 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
         // ---- RANSAC ----------------------------------------------------------------------------------
         {
             ArenaMark m3(ctx);
-            double *hyp_T, *hyp_err2; unsigned char* hyp_valid; int *hyp_inl, *n_active;
-            IBL_ARENA(hyp_T, double, (int64_t)J * HB * 12);
-            IBL_ARENA(hyp_err2, double, (int64_t)J * HB);
-            IBL_ARENA(hyp_inl, int, (int64_t)J * HB);
-            IBL_ARENA(hyp_valid, unsigned char, (int64_t)J * HB);
-            IBL_ARENA(n_active, int, 64);
             const double max_dist = voxel_size * global_dist_factor;
+            const int max_round = RANSAC_MAX_ROUND;
+            const int max_blk = max_round / 256;
+            float4* cp; unsigned char* flags; int *blk_cnt, *blk_off, *list, *n_active;
+            IBL_ARENA(cp, float4, 2 * (int64_t)Ns + 2);
+            IBL_ARENA(flags, unsigned char, (int64_t)J * max_round);
+            IBL_ARENA(blk_cnt, int, (int64_t)J * max_blk + 1);
+            IBL_ARENA(blk_off, int, (int64_t)J * max_blk + 1);
+            IBL_ARENA(n_active, int, 64);
+            const int list_cap = (int)std::min<int64_t>((int64_t)J * max_round / 16 + 65536, (int64_t)1 << 27);
+            IBL_ARENA(list, int, list_cap);
+            int* e_inl; double *e_err2, *e_T;
+            IBL_ARENA(e_inl, int, list_cap);
+            IBL_ARENA(e_err2, double, list_cap);
+            IBL_ARENA(e_T, double, (int64_t)list_cap * 12);
+            size_t tmp_bytes = 0;
+            IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, blk_cnt, blk_off, J * max_blk + 1, s));
+            unsigned char* tmp;
+            IBL_ARENA(tmp, unsigned char, (int64_t)tmp_bytes + 256);
+            hipLaunchKernelGGL(ibl_pack_corr_kernel, dim3(16, J), dim3(256), 0, s, P, d_job_off, J, corr, n_corr, cp);
+            IBL_LAUNCH_CHECK();
             hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist);
             IBL_LAUNCH_CHECK();
-            const long long max_rounds = (ransac_max_iter + HB - 1) / HB;
-            for (long long round = 0; round < max_rounds; ++round) {
-                hipLaunchKernelGGL(ibl_ransac_hyp_kernel, dim3(HB / 256, J), dim3(256), 0, s, rs, P, d_job_off, J, corr, n_corr, max_dist, 0.9,
-                                   (unsigned)seed, (unsigned)(seed >> 32), job_id_base, hyp_T, hyp_valid);
+            long long walked = 0;
+            int round_size = RANSAC_FIRST_ROUND;
+            while (walked < ransac_max_iter) {
+                const int nblk = round_size / 256;
+                hipLaunchKernelGGL(ibl_ransac_flag_kernel, dim3(nblk, J), dim3(256), 0, s, rs, cp, d_job_off, n_corr, (long long)ransac_max_iter,
+                                   max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags, blk_cnt);
                 IBL_LAUNCH_CHECK();
-                hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3(HB / 4, J), dim3(256), 0, s, P, d_job_off, J, corr, n_corr, max_dist, hyp_T,
-                                   hyp_valid, hyp_inl, hyp_err2);
-                IBL_LAUNCH_CHECK();
-                IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
-                hipLaunchKernelGGL(ibl_ransac_scan_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99,
-                                   hyp_T, hyp_valid, hyp_inl, hyp_err2, n_active);
-                IBL_LAUNCH_CHECK();
-                if ((round & 3) == 3 || round + 1 == max_rounds || round < 2) {
-                    int h_active = 0;
-                    IBL_HIP_CHECK(hipMemcpyAsync(&h_active, n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-                    IBL_HIP_CHECK(hipStreamSynchronize(s));
-                    if (h_active == 0) break;
+                IBL_HIP_CHECK(hipMemsetAsync(blk_cnt + (int64_t)J * nblk, 0, sizeof(int), s));
+                IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, J * nblk + 1, s));
+                int total = 0;
+                IBL_HIP_CHECK(hipMemcpyAsync(&total, blk_off + (int64_t)J * nblk, sizeof(int), hipMemcpyDeviceToHost, s));
+                IBL_HIP_CHECK(hipStreamSynchronize(s));
+                if (total > list_cap) return ibl_set_error(IBL_ERR_OVERFLOW, "ransac: %d surviving hypotheses in one round exceed the list capacity %d", total, list_cap);
+                if (total > 0) {
+                    hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, J), dim3(256), 0, s, flags, blk_off, round_size, list);
+                    IBL_LAUNCH_CHECK();
+                    hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3((total + 3) / 4), dim3(256), 0, s, rs, cp, d_job_off, n_corr, J, max_dist, 0.9,
+                                       (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total, e_inl, e_err2, e_T);
+                    IBL_LAUNCH_CHECK();
                 }
+                IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
+                hipLaunchKernelGGL(ibl_ransac_fold_kernel, dim3(J), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99, round_size,
+                                   blk_off, list, e_inl, e_err2, e_T, total, n_active);
+                IBL_LAUNCH_CHECK();
+                int h_active = 0;
+                IBL_HIP_CHECK(hipMemcpyAsync(&h_active, n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+                IBL_HIP_CHECK(hipStreamSynchronize(s));
+                walked += round_size;
+                if (h_active == 0) break;
+                if (round_size < max_round) round_size = std::min(max_round, round_size * 8);
             }
         }
         // ---- colour gradients of the targets --------------------------------------------------------
