@@ -114,6 +114,11 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
     from oracle import reg_oracle as ro
     from oracle import vit_oracle as vo
 
+    import torch
+    threads = min(16, os.cpu_count() or 1)          # the GPU box gives one GPU's share of 16 host cores
+    torch.set_num_threads(threads)
+    from oracle.clib import lib as olib
+    olib.oracle_set_threads(threads)
     cfg = V.CONFIGS[args.model]
     w = V.random_weights(cfg, 20)
     crops = batch["crops"].cpu().numpy()
@@ -140,7 +145,7 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
         ro.localise_from_assignments(cleaned, cint, world.points, world.colors, assns, 0.05, 1.5, 1.5, seed=args.seed)
         row += q
     dt = time.time() - t0
-    return n_frames / dt, dt
+    return n_frames / dt, dt, threads
 
 
 def main():
@@ -148,7 +153,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=16, help="query frames per step and per GPU")
+    ap.add_argument("--frames", type=int, default=32, help="query frames per step and per GPU")
     ap.add_argument("--memory", type=int, default=1000)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--points", type=int, default=5000)
@@ -156,7 +161,7 @@ def main():
     ap.add_argument("--model", default="dinov2_vitb14")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--arena-gb", type=float, default=24.0)
-    ap.add_argument("--cpu-frames", type=int, default=1, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-kernel", default="", help="(internal) name of the kernel the roofline is reported for")
     args = ap.parse_args()
 
@@ -210,8 +215,8 @@ def main():
         roof = prof.roofline()
         cpu = None
         if args.cpu_frames > 0:
-            v, cdt = cpu_baseline(args, world, mem_emb, batches[args.warmup], args.cpu_frames)
-            cpu = {"value": v, "unit": "query-frames/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+            v, cdt, threads = cpu_baseline(args, world, mem_emb, batches[args.warmup], args.cpu_frames)
+            cpu = {"value": v, "unit": "query-frames/s", "cores": threads,
                    "kind": "port", "sample": f"{args.cpu_frames} frame(s) of the same workload, {cdt:.1f} s: torch-cpu fp32 ViT + "
                    "C oracle (match, FPFH, RANSAC, coloured ICP, evaluate; OpenMP) + host assignment search"}
         out = {

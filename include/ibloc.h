@@ -34,6 +34,13 @@ extern "C" {
 int ibl_version(void);
 const char* ibl_last_error(void);
 
+/* In-process kernel timer for the roofline line of bench.py: when enabled, selected kernel families are
+ * bracketed by HIP events ON THEIR LAUNCH STREAM.  ibl_prof_read synchronises those events and returns the
+ * accumulated device time, the accumulated algorithmic units (FLOPs or bytes, see csrc/ibl_common.h) and the
+ * number of launches of family `id` (1 = bf16 GEMM, 3 = SPFH k-NN, ...). */
+int ibl_prof_enable(int on);
+int ibl_prof_read(int id, double* ms, double* units, int64_t* launches);
+
 /* ------------------------------------------------------------------------------------------ */
 /* embed: crop preprocessing + ViT encoder forward                       */
 /* ------------------------------------------------------------------------------------------ */

@@ -30,6 +30,8 @@ vp = C.c_void_p
 _SIGS = {
     "ibl_version": (C.c_int, []),
     "ibl_last_error": (C.c_char_p, []),
+    "ibl_prof_enable": (C.c_int, [C.c_int]),
+    "ibl_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ibl_normalize_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "ibl_closest_similarity_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "ibl_closest_similarity": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, vp, vp, vp,

@@ -24,4 +24,19 @@ int ibl_set_error(int code, const char* fmt, ...);
 #define IBL_LAUNCH_CHECK() IBL_HIP_CHECK(hipGetLastError())
 #endif
 
+// kernel-family ids of the in-process timer (ibl_prof_*), units = algorithmic FLOPs or bytes per launch
+#define IBL_PROF_GEMM 1        // ibl_gemm_bf16_tn (all epilogues): units = 2*M*N*K FLOPs
+#define IBL_PROF_ATTN 2        // ibl_attention_kernel: 4*T*T*64 FLOPs per (crop, head)
+#define IBL_PROF_SPFH 3        // ibl_spfh_kernel: 156 B per point (24 in + 132 out)
+#define IBL_PROF_NORMALS 4     // ibl_normals_kernel: 24 B per point
+#define IBL_PROF_FPFH 5        // ibl_fpfh_kernel: 264 B per point
+#define IBL_PROF_FEATNN 6      // ibl_feat_nn_kernel: 2*33*Ns*Nt FLOPs per direction
+#define IBL_PROF_ICP 7         // ibl_icp_step_kernel: 56 B per source point
+#define IBL_PROF_RANSAC 8      // ibl_ransac_flag_kernel: hypotheses
+#define IBL_PROF_ROWSIM 9      // ibl_rowsim_kernel: 2*rows*queries*dim FLOPs
+#define IBL_PROF_MAX 16
+int ibl_prof_enabled();
+void ibl_prof_begin(int id, double units, void* stream, void** token);
+void ibl_prof_end(void* token, void* stream);
+
 static inline int64_t ibl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

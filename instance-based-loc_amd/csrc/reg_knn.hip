@@ -597,8 +597,11 @@ int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off
 int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
                     float* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s) {
     if (n <= 0) return IBL_OK;
+    void* tok;
+    ibl_prof_begin(IBL_PROF_SPFH, 156.0 * (double)n, s, &tok);
     hipLaunchKernelGGL(ibl_spfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, (float)radius,
                        (float)(radius * radius), max_nn, spfh, nbr_idx, nbr_d2, nbr_cnt, status);
+    ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, fpfh);
     IBL_LAUNCH_CHECK();

@@ -183,7 +183,10 @@ static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    void* tok;
+    ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);
     hipLaunchKernelGGL(ibl_gemm_bf16_tn<EPI>, dim3(nwg), dim3(256), lds, s, A, lda, W, ldw, M, N, K, epi);
+    ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
 }

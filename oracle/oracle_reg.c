@@ -23,6 +23,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { omp_set_num_threads(n); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+#endif
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
