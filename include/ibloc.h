@@ -178,6 +178,8 @@ int ibl_assign_batch(const uint16_t* aug_half, const int32_t* q_per_frame, int n
 typedef struct ibl_reg_ctx ibl_reg_ctx;
 int ibl_reg_ctx_create(ibl_reg_ctx** out, int64_t arena_bytes);
 int ibl_reg_ctx_destroy(ibl_reg_ctx* ctx);
+/* drop every allocation of the arena, including memory grids built from it (they become invalid) */
+int ibl_reg_ctx_reset(ibl_reg_ctx* ctx);
 int64_t ibl_reg_ctx_high_water(const ibl_reg_ctx* ctx);
 /* device status word (bit 0: grid table overflow, bit 1: a k-NN query took the re-scan slow path);
  * synchronises the device */

@@ -42,6 +42,7 @@ _SIGS = {
     "ibl_vit_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),
     "ibl_reg_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int64]),
     "ibl_reg_ctx_destroy": (C.c_int, [vp]),
+    "ibl_reg_ctx_reset": (C.c_int, [vp]),
     "ibl_reg_ctx_high_water": (C.c_int64, [vp]),
     "ibl_reg_ctx_status": (C.c_int, [vp, C.c_int]),
     "ibl_radius_outlier_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp]),

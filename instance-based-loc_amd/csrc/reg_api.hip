@@ -42,6 +42,12 @@ extern "C" int ibl_reg_ctx_destroy(ibl_reg_ctx* ctx) {
     return IBL_OK;
 }
 
+extern "C" int ibl_reg_ctx_reset(ibl_reg_ctx* ctx) {
+    if (!ctx) return ibl_set_error(IBL_ERR_ARG, "ibl_reg_ctx_reset: null context");
+    ctx->used = 256;           // drops every persistent allocation (memory grids built from this arena become invalid)
+    return IBL_OK;
+}
+
 extern "C" int64_t ibl_reg_ctx_high_water(const ibl_reg_ctx* ctx) { return ctx ? ctx->high_water : -1; }
 
 extern "C" int ibl_reg_ctx_status(ibl_reg_ctx* ctx, int clear) {

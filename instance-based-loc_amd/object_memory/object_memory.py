@@ -1,0 +1,167 @@
+"""Drop-in for the query side of the reference's `object_memory/object_memory.py` on the MI355X build.
+
+`ObjectMemory.localise()` keeps the reference's keyword list and return shape
+(/root/reference/object_memory/object_memory.py:852-863, 896, 1169); everything from the embedding of the object
+crops to the returned pose runs through the batched HIP engine (ibloc_amd.engine).  The perception front end
+(RAM + GroundingDINO + SAM, object_memory/object_finder.py) is out of scope for this build: pass any callable with
+the reference's `ObjectFinder.find` contract as `object_finder=` (find(rgb_path, consider_floor) ->
+(grounded_imgs, bounding_boxes, masks, phrases) or (None, None, None, None)).  Memory construction
+(process_image / reclustering) is offline and also out of scope; `add_object()` / `load_objects()` fill the memory
+with (name, embeddings, cloud) records in the reference's ObjectInfo layout.
+"""
+import os
+
+import numpy as np
+import torch
+
+from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+from ibloc_amd.registration import CloudBatch, RegContext, radius_outlier_batch
+from ibloc_amd.utils.fpfh_register import Cloud
+
+from .object_info import ObjectInfo
+
+DEFAULT_OUTLIER_REMOVAL_CONFIG = {"radius_nb_points": 12, "radius": 0.05}      # utils/depth_utils.py:5-10
+
+
+def default_load_rgb(path: str) -> np.ndarray:
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def default_load_depth(path: str) -> np.ndarray:
+    if path.split('.')[-1] == 'npy':
+        return np.load(path)
+    from PIL import Image
+    return np.asarray(Image.open(path))
+
+
+def coloured_pointcloud_from_depth(depth_image, rgb_image, fx, fy):
+    """utils/depth_utils.py:46-90 without the outlier step: centred pixel grid (note the reference's swapped w/h names),
+    drop z == 0, colours / 255."""
+    assert depth_image.shape[:2] == rgb_image.shape[:2], "Depth and RGB image dimensions do not match"
+    w, h = depth_image.shape
+    horizontal = np.tile(np.linspace(-h / 2, h / 2, h, dtype=np.float32), (w, 1))
+    vertical = np.tile(np.linspace(w / 2, -w / 2, w, dtype=np.float32).reshape(-1, 1), (1, h))
+    X = horizontal * depth_image / fx
+    Y = vertical * depth_image / fy
+    pts = np.stack([X, Y, depth_image], axis=2).reshape(-1, 3)
+    valid = pts[:, 2] != 0
+    cols = (rgb_image.astype(np.float32) / 255.0).reshape(-1, 3)[valid]
+    return pts[valid], cols
+
+
+class ObjectMemory():
+    def __init__(self, device, ram_pretrained_path=None, sam_checkpoint_path=None, camera_focal_lenth_x=None,
+                 camera_focal_lenth_y=None, get_embeddings_func=None, log_enabled=True,
+                 mem_formation_bounding_box_threshold=0.3, mem_formation_occlusion_overlap_threshold=0.9,
+                 object_info_max_embeddings_num=1000000, load_rgb_image_func=default_load_rgb,
+                 load_depth_image_func=default_load_depth, dataset_floor_thickness=0.1, lora_path=None,
+                 object_finder=None, arena_bytes=8 << 30):
+        if get_embeddings_func is None:
+            raise NotImplementedError("Need to pass in get_embeddings_func")       # reference :112
+        self.device = device
+        self.camera_focal_lenth_x = camera_focal_lenth_x
+        self.camera_focal_lenth_y = camera_focal_lenth_y
+        self.get_embeddings_func = get_embeddings_func
+        self.log_enabled = log_enabled
+        self.object_info_max_embeddings_num = object_info_max_embeddings_num
+        self.load_rgb_image_func = load_rgb_image_func
+        self.load_depth_image_func = load_depth_image_func
+        self.object_finder = object_finder
+        self.memory = []
+        self.floors = None
+        self._ctx = RegContext(arena_bytes)
+        self._engine = None
+        self.ransac_seed = 0
+        self._n_queries = 0
+
+    def __repr__(self):
+        return "".join(f"\t{o}\n" for o in self.memory) or "\tNo objects in memory yet."
+
+    # ---- memory content ---------------------------------------------------------------------------------
+    def add_object(self, name, embeddings, points, colors):
+        embs = [np.asarray(e) for e in embeddings]
+        info = ObjectInfo(len(self.memory), name, embs[0], Cloud(points, colors), self.object_info_max_embeddings_num)
+        info.embeddings = embs
+        info._compute_means()
+        self.memory.append(info)
+        self._engine = None
+
+    def _get_engine(self):
+        if self._engine is None:
+            if not self.memory:
+                raise RuntimeError("object memory is empty")
+            self._ctx.reset()
+            shard = MemoryShard(self._ctx, [np.stack(m.embeddings).astype(np.float32) for m in self.memory],
+                                [np.asarray(m.pointcloud.points) for m in self.memory],
+                                colors=[np.asarray(m.pointcloud.colors) for m in self.memory], device=self.device)
+            self._engine = LocaliseEngine(shard)
+        return self._engine
+
+    # ---- query ------------------------------------------------------------------------------------------
+    def _get_object_info(self, rgb_image_path, depth_image_path, consider_floor, outlier_removal_config, depth_factor=1.):
+        """object_memory.py:125-161: one get_embeddings_func call per detected object, depth -> coloured clouds per mask."""
+        if self.object_finder is None:
+            raise RuntimeError("no object_finder: the RAM/GroundingDINO/SAM front end is outside this build; pass object_finder=")
+        imgs, boxes, masks, phrases = self.object_finder(rgb_image_path, consider_floor)
+        if imgs is None:
+            return None, None, None
+        rgb = self.load_rgb_image_func(rgb_image_path)
+        depth = self.load_depth_image_func(depth_image_path)
+        embs = np.stack([np.array(self.get_embeddings_func(
+            current_obj_grounded_img=imgs[i], current_obj_bounding_box=boxes[i], current_obj_mask=masks[i],
+            current_obj_phrase=phrases[i], full_rgb_image=rgb, full_depth_image=depth, consider_floor=consider_floor,
+            device=self.device).cpu()) for i in range(len(imgs))])
+        clouds = []
+        for m in masks:
+            m2 = np.asarray(m.cpu() if hasattr(m, "cpu") else m).reshape(depth.shape[:2])
+            pts, cols = coloured_pointcloud_from_depth((depth / depth_factor) * m2, rgb, self.camera_focal_lenth_x,
+                                                       self.camera_focal_lenth_y)
+            clouds.append((pts, cols))
+        if outlier_removal_config is not None and clouds:
+            b = CloudBatch.from_numpy([c[0] for c in clouds], device=self.device)
+            keep = radius_outlier_batch(self._ctx, b, outlier_removal_config["radius"], outlier_removal_config["radius_nb_points"])
+            keep = keep.cpu().numpy().astype(bool)
+            off = b.seg_off_host
+            clouds = [(c[0][keep[off[i]:off[i + 1]]], c[1][keep[off[i]:off[i + 1]]]) for i, c in enumerate(clouds)]
+        return phrases, embs, clouds
+
+    def localise_detections(self, detected_embs, detected_clouds, outlier_removal_config=None, fpfh_global_dist_factor=2,
+                            fpfh_local_dist_factor=0.4, fpfh_voxel_size=0.05, max_detected_object_num=7):
+        """The body of localise() after perception (object_memory.py:899-1131) for one frame: embeddings (Q, D) and
+        clouds [(points, colors), ...] -> FrameResult."""
+        if outlier_removal_config is None:
+            outlier_removal_config = {"radius_nb_points": 8, "radius": 0.05}
+        order = list(range(len(detected_clouds)))
+        if len(detected_clouds) > max_detected_object_num:                       # :900-908 keep the largest, reorder
+            order = sorted(order, key=lambda i: len(detected_clouds[i][0]), reverse=True)[:max_detected_object_num]
+        embs = np.asarray(detected_embs, dtype=np.float32)[order]
+        clouds = [detected_clouds[i] for i in order]
+        det = CloudBatch.from_numpy([c[0] for c in clouds], [intensity_from_colors(c[1]) for c in clouds], device=self.device)
+        self._n_queries += 1
+        eng = self._get_engine()
+        return eng.localise_batch(det, [len(clouds)], det_emb=embs, fpfh_voxel_size=fpfh_voxel_size,
+                                  fpfh_global_dist_factor=fpfh_global_dist_factor, fpfh_local_dist_factor=fpfh_local_dist_factor,
+                                  outlier_radius=outlier_removal_config["radius"], outlier_nb_points=outlier_removal_config["radius_nb_points"],
+                                  seed=self.ransac_seed, job_id_base=16 * self._n_queries)[0]
+
+    def localise(self, image_path, depth_image_path, testname="", subtest_name="", save_point_clouds=False,
+                 outlier_removal_config=None, fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, fpfh_voxel_size=0.05,
+                 topK=5, useLora=True, save_localised_pcd_path=None, consider_floor=False, perform_semantic_icp=True,
+                 depth_factor=1., max_detected_object_num=7):
+        if outlier_removal_config is None:
+            outlier_removal_config = {"radius_nb_points": 8, "radius": 0.05}
+        consider_floor = False                                                        # :886
+        phrases, embs, clouds = self._get_object_info(image_path, depth_image_path, consider_floor, outlier_removal_config,
+                                                      depth_factor)
+        if embs is None:
+            return np.array([0., 0., 0., 0., 0., 0., 1.]), [[], []]                   # :895-896
+        if perform_semantic_icp:
+            raise NotImplementedError                                                  # :1039-1040 (every driver passes False)
+        save_root = f"pcds/{testname}/"                                               # side effect of the reference (:947-950)
+        if not os.path.exists(save_root):
+            os.makedirs(save_root)
+        res = self.localise_detections(embs, clouds, outlier_removal_config, fpfh_global_dist_factor, fpfh_local_dist_factor,
+                                       fpfh_voxel_size, max_detected_object_num)
+        last = res.assignments[-1] if res.assignments else []
+        return res.pose, [last, None]                                                 # :1169 (assn of the last loop iteration)

@@ -36,6 +36,9 @@ class RegContext:
     def handle(self):
         return self._h
 
+    def reset(self):
+        _lib.check(_lib.lib.ibl_reg_ctx_reset(self._h), "ibl_reg_ctx_reset")
+
     def status(self, clear=True):
         return _lib.lib.ibl_reg_ctx_status(self._h, 1 if clear else 0)
 

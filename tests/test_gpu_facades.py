@@ -1,0 +1,113 @@
+"""-m gpu: the reference-shaped Python surface (utils.fpfh_register, utils.embeddings, ObjectMemory.localise)."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial.transform import Rotation
+
+from ibloc_amd.synth import SynthWorld
+from oracle import reg_oracle as ro
+from oracle import vit_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def rot_deg(A, B):
+    return float(np.degrees(np.arccos(np.clip((np.trace(A[:3, :3].T @ B[:3, :3]) - 1) / 2, -1, 1))))
+
+
+def test_fpfh_register_facade():
+    from ibloc_amd.utils import fpfh_register as fr
+    w = SynthWorld(2, pts_per_object=2500, E=1, D=8, seed=41)
+    tgt = (w.points[0] - w.points[0].mean(0))
+    R = Rotation.from_euler("xyz", [25, -10, 40], degrees=True).as_matrix()
+    t = np.array([0.2, 0.1, -0.15])
+    rng = np.random.default_rng(1)
+    src_w, src_c = w.objects[0].sample(2500, rng)
+    src = ((src_w - w.points[0].mean(0)) - t) @ R                      # tgt ~= R src + t
+    down, feat = fr.downsample_and_compute_fpfh(fr.Cloud(src, src_c), 0.05)
+    assert feat.data.shape == (33, len(src)) and down.normals.shape == src.shape
+    assert np.allclose(np.linalg.norm(down.normals, axis=1), 1, atol=1e-4)
+    T, rmse, fit = fr.register_point_clouds((src, src_c), (tgt, w.colors[0]), 0.05, 1.5, 1.5)
+    assert T.shape == (4, 4) and fit > 0.9
+    assert rot_deg(T, np.vstack([np.c_[R, t], [0, 0, 0, 1]])) < 2.0 and np.linalg.norm(T[:3, 3] - t) < 0.03
+    er, ef = fr.evaluate_transform(src, tgt, T, 0.02)
+    orr, of = ro.evaluate(src.astype(np.float32), tgt.astype(np.float32), T, 0.02)
+    assert abs(ef - of) < 2.0 / len(src) and abs(er - orr) < 1e-5
+    # no colours -> the reference's exception path: point-to-point ICP from identity on the raw clouds
+    T2, rmse2, fit2 = fr.register_point_clouds(src, tgt, 0.05, 1.5, 1.5)
+    To, fo, ro_, it = ro.icp(src.astype(np.float32), None, tgt.astype(np.float32), None, None, None, 0.075, np.eye(4), colored=False)
+    assert np.allclose(T2, To, atol=1e-6)
+    # numpy Kabsch helpers: reference test.py case 1
+    Tk = fr.get_SVD_transform(np.eye(3), np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]]))
+    assert np.allclose(Tk[:3, :3], [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-12)
+
+
+def test_embeddings_facade():
+    from ibloc_amd import vit as V
+    from ibloc_amd import preprocess as pp
+    from ibloc_amd.utils import embeddings as emb
+    with pytest.raises(RuntimeError):
+        emb.get_all_vit_embeddings(current_obj_grounded_img=np.zeros((50, 50, 3), np.uint8))
+    cfg = V.CONFIGS["tiny_dino"]
+    w = V.random_weights(cfg, 2)
+    emb.set_encoder("dino", V.VitEncoder(cfg, w))
+    crop = np.random.default_rng(0).integers(0, 256, size=(120, 90, 3), dtype=np.uint8)
+    out = emb.get_all_dino_embeddings(current_obj_grounded_img=crop, current_obj_phrase="x", device="cuda", extra_kwarg=1)
+    assert isinstance(out, torch.Tensor) and out.dim() == 1 and out.shape[0] == cfg.dim
+    exp = vo.embed_crops(w, cfg, pp.RECIPES["dinov2"], [crop])[0]
+    got = np.array(out.cpu())
+    assert np.linalg.norm(got - exp) / np.linalg.norm(exp) < 2e-2
+    ccfg = V.CONFIGS["tiny_clip"]
+    cw = V.random_weights(ccfg, 3)
+    emb.set_encoder("clip", V.VitEncoder(ccfg, cw))
+    c = emb.get_all_clip_embeddings(current_obj_grounded_img=crop)
+    assert abs(float(c.norm()) - 1.0) < 1e-5                           # L2-normalised like the reference (:48)
+    with pytest.raises(NotImplementedError):
+        emb.get_dator_embeddings(current_obj_grounded_img=crop)
+
+
+def test_object_memory_localise_with_stub_finder(tmp_path):
+    from ibloc_amd.object_memory.object_memory import ObjectMemory
+    w = SynthWorld(4, pts_per_object=2500, E=2, D=32, seed=51)
+    rng = np.random.default_rng(52)
+    f = w.make_frame(rng, q=2, pts_per_object=2500, anchor=0)
+    dummy = lambda **kw: torch.tensor(kw["full_rgb_image"][0, 0, :1].astype(np.float32))
+    with pytest.raises(NotImplementedError):
+        ObjectMemory("cuda", get_embeddings_func=None)
+    # --- detections API (perception bypassed) vs the oracle transcript
+    om = ObjectMemory("cuda", None, None, 300.0, 300.0, get_embeddings_func=dummy)
+    for j in range(w.M):
+        om.add_object(f"obj{j}", list(w.embeddings[j]), w.points[j], w.colors[j])
+    res = om.localise_detections(f["det_emb"], f["clouds"], fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
+    assert res.pose.shape == (7,) and len(res.assignments) >= 1
+    cleaned, ccols = [], []
+    for (p, c) in f["clouds"]:
+        k = ro.radius_outlier(p.astype(np.float32), 0.05, 8)
+        cleaned.append(p[k]); ccols.append(c[k])
+    pose, recs, best = ro.localise_from_assignments(cleaned, ccols, w.points, w.colors, res.assignments, 0.05, 1.5, 1.5, seed=0,
+                                                    job_base=16, stale_means=True)
+    assert res.best == best and np.linalg.norm(res.pose[:3] - pose[:3]) <= 0.01
+    # --- full localise() through a stub ObjectFinder on a rendered depth image: no detections -> reference default
+    rgb = np.zeros((60, 80, 3), np.uint8)
+    depth = np.zeros((60, 80), np.float32)
+    from PIL import Image
+    Image.fromarray(rgb).save(tmp_path / "rgb.png")
+    np.save(tmp_path / "depth.npy", depth)
+    om.object_finder = lambda path, consider_floor: (None, None, None, None)
+    pose0, extra = om.localise(str(tmp_path / "rgb.png"), str(tmp_path / "depth.npy"), perform_semantic_icp=False)
+    assert np.array_equal(pose0, [0, 0, 0, 0, 0, 0, 1]) and extra == [[], []]
+    # one flat synthetic object seen by the stub finder: exercises unprojection + outlier removal + the engine call
+    depth[10:50, 10:70] = 2.0 + 0.05 * np.sin(np.arange(60)[None, :] / 5.0)
+    rgb[10:50, 10:70] = 128
+    np.save(tmp_path / "depth.npy", depth)
+    Image.fromarray(rgb).save(tmp_path / "rgb.png")
+    mask = torch.zeros((1, 60, 80), dtype=torch.bool)
+    mask[0, 10:50, 10:70] = True
+    om.object_finder = lambda path, consider_floor: ([rgb[10:50, 10:70]], [torch.tensor([10., 10., 70., 50.])], [mask], ["thing"])
+    om.get_embeddings_func = lambda **kw: torch.from_numpy(w.embeddings[1][0]).cuda()
+    with pytest.raises(NotImplementedError):
+        om.localise(str(tmp_path / "rgb.png"), str(tmp_path / "depth.npy"))           # perform_semantic_icp=True default raises
+    pose1, extra1 = om.localise(str(tmp_path / "rgb.png"), str(tmp_path / "depth.npy"), testname=str(tmp_path / "t"),
+                                perform_semantic_icp=False, outlier_removal_config={"radius_nb_points": 2, "radius": 0.2})
+    assert pose1.shape == (7,) and np.isfinite(pose1).all() and extra1[1] is None
+    assert extra1[0][0][1] == 1                                          # matched the instance whose embedding was returned

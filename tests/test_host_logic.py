@@ -1,0 +1,100 @@
+"""CPU: host-side logic of the product (resample tables vs PIL, recipes, sharding helpers, gloo all-gather)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+from PIL import Image
+
+from ibloc_amd import preprocess as pp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _emulate(img, recipe):
+    h, w, _ = img.shape
+    rh, rw, top, left = pp.resized_size(recipe, h, w)
+
+    def one_pass(arr, in_size, out_size, win0, win_n, axis):
+        if in_size == out_size:
+            return np.take(arr, np.arange(win0, win0 + win_n), axis=axis)
+        rec, ks = pp.resample_table(in_size, out_size, recipe.filt, win0, win_n)
+        arr = np.moveaxis(arr, axis, 0).astype(np.int64)
+        out = np.zeros((win_n,) + arr.shape[1:], dtype=np.int64)
+        for i in range(win_n):
+            x0, n = rec[i, 0], rec[i, 1]
+            acc = np.full(arr.shape[1:], 1 << (pp.PRECISION_BITS - 1), dtype=np.int64)
+            for t in range(n):
+                acc += arr[x0 + t] * int(rec[i, 2 + t])
+            out[i] = np.clip(acc >> pp.PRECISION_BITS, 0, 255)
+        return np.moveaxis(out.astype(np.uint8), 0, axis)
+
+    return one_pass(one_pass(img, w, rw, left, recipe.out_w, 1), h, rh, top, recipe.out_h, 0)
+
+
+def test_resample_tables_are_bit_exact_vs_pil():
+    rng = np.random.default_rng(0)
+    for name in ("dinov2", "vit", "clip", "dator_rgb"):
+        r = pp.RECIPES[name]
+        for (h, w) in [(224, 224), (64, 400), (333, 97), (500, 375), (257, 300)]:
+            img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            rh, rw, top, left = pp.resized_size(r, h, w)
+            res = Image.fromarray(img).resize((rw, rh), resample=Image.BICUBIC if r.filt == "bicubic" else Image.BILINEAR)
+            ref = np.asarray(res)[top:top + r.out_h, left:left + r.out_w]
+            assert np.array_equal(_emulate(img, r), ref), (name, h, w)
+
+
+def test_plan_batch_shares_tables():
+    descs, tables, src_bytes, tmp_bytes, max_h = pp.plan_batch(pp.RECIPES["dinov2"], [(224, 224)] * 5 + [(100, 300)])
+    assert descs[0].h_table == descs[4].h_table and descs[5].h_table != descs[0].h_table
+    assert src_bytes == 5 * 224 * 224 * 3 + 100 * 300 * 3 and max_h == 224
+
+
+def test_shard_ranges_cover_everything():
+    from ibloc_amd.parallel import shard_range
+    for n in (0, 1, 7, 1000, 50001):
+        for w in (1, 2, 8):
+            got = [shard_range(n, r, w) for r in range(w)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(got[:-1], got[1:]))
+            assert max(b - a for a, b in got) - min(b - a for a, b in got) <= 1
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["IBL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from ibloc_amd.parallel import shard_range, allgather_similarity_blocks, augment_half, frames_for_rank
+from ibloc_amd.assign import assign_batch
+from oracle import match_oracle as mo
+from oracle import simvolume_oracle as so
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(5)
+M, E, D, Q = 37, 3, 64, 5
+mem = mo.normalize_rows(rng.normal(size=(M * E, D)).astype(np.float32))
+det = mo.normalize_rows(rng.normal(size=(Q, D)).astype(np.float32))
+off = (np.arange(M + 1) * E).astype(np.int32)
+lo, hi = shard_range(M, rank, world)
+local = mo.closest_similarity(det, mem[lo * E:hi * E], (off[lo:hi + 1] - off[lo]).astype(np.int32))   # this rank's instance shard
+full = allgather_similarity_blocks(torch.from_numpy(local), M)
+exp = mo.closest_similarity(det, mem, off)
+assert np.array_equal(full.numpy(), exp), "gathered similarity matrix differs"
+aug = augment_half(full)
+got = assign_batch(aug[None], [Q], 4, 1)[0]
+assert got == so.simvolume_assignments(exp, 4)
+assert list(frames_for_rank(10, rank, world)) == list(range(*shard_range(10, rank, world)))
+dist.barrier()
+if rank == 0:
+    print("GLOO_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_match_allgather_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, IBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GLOO_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
