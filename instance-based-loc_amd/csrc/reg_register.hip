@@ -642,14 +642,21 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
     const double max_dist_icp = voxel_size * local_dist_factor;
     int st;
 
-    // grid A (cell = normal radius) lives until the end: normals, colour gradients, ICP neighbours
-    BatchGrid gA;
-    st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(voxel_size * 2), (int64_t)128 << 20, &gA, s);
+    // grid C (cell = ICP correspondence distance) lives until the end: ICP neighbours (reach 1) and colour gradients
+    // (radius 2 * max_dist, reach 2); grid A (cell = normal radius) only serves the normals
+    BatchGrid gC;
+    st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)max_dist_icp, (int64_t)128 << 20, &gC, s);
     if (st) return st;
     float4* grad = nullptr;
     if (colored) {
-        st = ibl_launch_normals(gA, P, d_job_off, N, voxel_size * 2, 30, normals, ctx->d_status, s);
-        if (st) return st;
+        {
+            ArenaMark mA(ctx);
+            BatchGrid gA;
+            st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(voxel_size * 2), (int64_t)128 << 20, &gA, s);
+            if (st) return st;
+            st = ibl_launch_normals(gA, P, d_job_off, N, voxel_size * 2, 30, normals, ctx->d_status, s);
+            if (st) return st;
+        }
         IBL_ARENA(rs, RansacState, J);
         int2* corr; int* n_corr;
         IBL_ARENA(corr, int2, Ns + 1);
@@ -736,7 +743,7 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
         }
         // ---- colour gradients of the targets --------------------------------------------------------
         IBL_ARENA(grad, float4, N + 1);
-        st = ibl_launch_color_grad(gA, P, normals, d_job_off, Ns, N, max_dist_icp * 2.0, 30, grad, ctx->d_status, s);
+        st = ibl_launch_color_grad(gC, P, normals, d_job_off, Ns, N, max_dist_icp * 2.0, 30, grad, ctx->d_status, s);
         if (st) return st;
     }
     // ---- ICP ------------------------------------------------------------------------------------------
@@ -748,7 +755,7 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
         const double lambda_geometric = 0.968;
         const int max_iter = 30;
         for (int it = 0; it <= max_iter; ++it) {
-            hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, gA, P, normals, grad, d_job_off, J, is,
+            hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, gC, P, normals, grad, d_job_off, J, is,
                                (float)max_dist_icp, (float)(max_dist_icp * max_dist_icp), colored ? 1 : 0, sqrt(lambda_geometric),
                                sqrt(1.0 - lambda_geometric), partial);
             IBL_LAUNCH_CHECK();

@@ -49,13 +49,22 @@ struct GemmEpi {
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
-constexpr int LDS_ROW = GBK * 2 + 16;   // bytes per tile row (128 B of data + 16 B pad)
+constexpr int LDS_ROW = GBK * 2;        // 128-byte tile rows, XOR-swizzled 16-byte chunks (no padding)
 
+// LDS images: a tile row holds 8 chunks of 16 bytes; chunk c of row r lives at chunk c ^ key(r).
+//   activation tile: key = r & 7            (fragment rows are consecutive -> conflict-free ds_read_b128)
+//   weight tile:     key = ((r >> 4) & 3) * 2 + ((r >> 1) & 1)   (fragment rows are 16a + 4j + b, see below)
+__device__ __forceinline__ int key_act(int r) { return r & 7; }
+__device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
+
+// C[M][N] = A[M][K] * W[N][K]^T.  The MFMA computes the TRANSPOSED tile (W is the A operand, the activations
+// the B operand) and MFMA row 4*fg + r of n-tile j is mapped to weight row 16*fg + 4*j + r, so that every lane
+// ends up with 16 CONSECUTIVE output columns of one output row: the epilogue is 16-byte vector stores.
 template <int EPI>
 __global__ __launch_bounds__(256) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
                                                         int64_t ldw, int M, int N, int K, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // buffer b: A tile at (2b) * GBM * LDS_ROW, B tile at (2b + 1) * GBM * LDS_ROW
+    // buffer b: activation tile at (2b) * GBM * LDS_ROW, weight tile at (2b + 1) * GBM * LDS_ROW
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -73,98 +82,145 @@ __global__ __launch_bounds__(256) void ibl_gemm_bf16_tn(const u16* __restrict__ 
     const int row0 = bm * GBM, col0 = bn * GBN;
 
     // staging: 1024 16-byte chunks per operand tile, 4 per thread
-    int ld_row[4], ld_c16[4];
+    int st_a[4], st_w[4];
     const u16* a_src[4];
     const u16* w_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + 256 * i;
-        ld_row[i] = c >> 3;
-        ld_c16[i] = c & 7;
-        int ar = row0 + ld_row[i];
+        const int r = c >> 3, ch = c & 7;
+        st_a[i] = r * LDS_ROW + ((ch ^ key_act(r)) << 4);
+        st_w[i] = r * LDS_ROW + ((ch ^ key_w(r)) << 4);
+        int ar = row0 + r;
         if (ar >= M) ar = M - 1;
-        a_src[i] = A + (int64_t)ar * lda + ld_c16[i] * 8;
-        w_src[i] = W + (int64_t)(col0 + ld_row[i]) * ldw + ld_c16[i] * 8;
+        a_src[i] = A + (int64_t)ar * lda + ch * 8;
+        w_src[i] = W + (int64_t)(col0 + r) * ldw + ch * 8;
     }
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (int64_t)kt * GBK);
-            rb[i] = *reinterpret_cast<const uint4*>(w_src[i] + (int64_t)kt * GBK);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(smem + (2 * buf) * GBM * LDS_ROW + ld_row[i] * LDS_ROW + ld_c16[i] * 16) = ra[i];
-            *reinterpret_cast<uint4*>(smem + (2 * buf + 1) * GBM * LDS_ROW + ld_row[i] * LDS_ROW + ld_c16[i] * 16) = rb[i];
-        }
-    };
+    // register staging of the next K tile (kept in named registers: a lambda / array-by-reference form is demoted
+    // to scratch memory by hipcc, which serialises every load behind a scratch store)
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GEMM_GLOAD(kt)                                                             \
+    do {                                                                           \
+        const int64_t _ko = (int64_t)(kt) * GBK;                                   \
+        ra0 = *reinterpret_cast<const uint4*>(a_src[0] + _ko);                     \
+        ra1 = *reinterpret_cast<const uint4*>(a_src[1] + _ko);                     \
+        ra2 = *reinterpret_cast<const uint4*>(a_src[2] + _ko);                     \
+        ra3 = *reinterpret_cast<const uint4*>(a_src[3] + _ko);                     \
+        rb0 = *reinterpret_cast<const uint4*>(w_src[0] + _ko);                     \
+        rb1 = *reinterpret_cast<const uint4*>(w_src[1] + _ko);                     \
+        rb2 = *reinterpret_cast<const uint4*>(w_src[2] + _ko);                     \
+        rb3 = *reinterpret_cast<const uint4*>(w_src[3] + _ko);                     \
+    } while (0)
+#define GEMM_LSTORE(buf)                                                           \
+    do {                                                                           \
+        unsigned char* _pa = smem + (2 * (buf)) * GBM * LDS_ROW;                   \
+        unsigned char* _pw = smem + (2 * (buf) + 1) * GBM * LDS_ROW;               \
+        *reinterpret_cast<uint4*>(_pa + st_a[0]) = ra0;                            \
+        *reinterpret_cast<uint4*>(_pa + st_a[1]) = ra1;                            \
+        *reinterpret_cast<uint4*>(_pa + st_a[2]) = ra2;                            \
+        *reinterpret_cast<uint4*>(_pa + st_a[3]) = ra3;                            \
+        *reinterpret_cast<uint4*>(_pw + st_w[0]) = rb0;                            \
+        *reinterpret_cast<uint4*>(_pw + st_w[1]) = rb1;                            \
+        *reinterpret_cast<uint4*>(_pw + st_w[2]) = rb2;                            \
+        *reinterpret_cast<uint4*>(_pw + st_w[3]) = rb3;                            \
+    } while (0)
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4];      // [m-tile i][n-tile j]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / GBK;
-    gload(0);
-    lstore(0);
+    GEMM_GLOAD(0);
+    GEMM_LSTORE(0);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
+    // fragment rows of this lane
+    int arow[4], wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        arow[i] = wm * 64 + i * 16 + fr;                             // activation row (B operand column)
+        wrow[i] = wn * 64 + 16 * (fr >> 2) + 4 * i + (fr & 3);       // weight row of MFMA row fr in n-tile i
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const unsigned char* pa = smem + (2 * buf) * GBM * LDS_ROW + (wm * 64 + fr) * LDS_ROW + fg * 16;
-        const unsigned char* pb = smem + (2 * buf + 1) * GBM * LDS_ROW + (wn * 64 + fr) * LDS_ROW + fg * 16;
+        if (kt + 1 < nk) GEMM_GLOAD(kt + 1);
+        const unsigned char* pa = smem + (2 * buf) * GBM * LDS_ROW;
+        const unsigned char* pw = smem + (2 * buf + 1) * GBM * LDS_ROW;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
+            const int ch = 4 * ks + fg;
+            bf16x8 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * LDS_ROW + ks * 64);
-                bfr[i] = *reinterpret_cast<const bf16x8*>(pb + i * 16 * LDS_ROW + ks * 64);
+                af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ key_act(arow[i])) << 4));
+                wf[i] = *reinterpret_cast<const bf16x8*>(pw + wrow[i] * LDS_ROW + ((ch ^ key_w(wrow[i])) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 1 < nk) GEMM_LSTORE(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue.  C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // epilogue.  D layout: col = lane & 15 -> output row m; MFMA row 4*fg + r of n-tile j -> output column 16*fg + 4*j + r
+    const int n0 = col0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
+    float bias[16], scale[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = col0 + wn * 64 + j * 16 + fr;
-        const float bias = epi.bias ? epi.bias[col] : 0.0f;
-        const float scale = (EPI == EPI_RESID_F32 && epi.scale) ? epi.scale[col] : 1.0f;
+    for (int q = 0; q < 4; ++q) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (epi.bias) b4 = *reinterpret_cast<const float4*>(epi.bias + n0 + 4 * q);
+        if (EPI == EPI_RESID_F32 && epi.scale) s4 = *reinterpret_cast<const float4*>(epi.scale + n0 + 4 * q);
+        bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
+        scale[4 * q] = s4.x; scale[4 * q + 1] = s4.y; scale[4 * q + 2] = s4.z; scale[4 * q + 3] = s4.w;
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wm * 64 + i * 16 + fr;
+        if (row >= M) continue;
+        float v[16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + wm * 64 + i * 16 + fg * 4 + r;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bias;
-                if (EPI == EPI_BIAS_BF16) {
-                    reinterpret_cast<u16*>(epi.out)[(int64_t)row * epi.ldo + col] = f2bf(v);
-                } else if (EPI == EPI_BIAS_GELU_BF16) {
-                    v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                    reinterpret_cast<u16*>(epi.out)[(int64_t)row * epi.ldo + col] = f2bf(v);
-                } else if (EPI == EPI_RESID_F32) {
-                    float* o = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + col;
-                    *o = *o + v * scale;
-                } else if (EPI == EPI_PATCH_F32) {
-                    const int b = row / epi.patches_per_crop, p = row - b * epi.patches_per_crop;
-                    const int64_t orow = (int64_t)b * epi.tokens_per_crop + 1 + p;
-                    reinterpret_cast<float*>(epi.out)[orow * epi.ldo + col] = v + epi.pos[(int64_t)p * N + col];
-                } else {
-                    reinterpret_cast<float*>(epi.out)[(int64_t)row * epi.ldo + col] = v;
-                }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
+        if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+            if (EPI == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = 0.5f * v[t] * (1.0f + erff(v[t] * 0.70710678118654752f));
             }
+            unsigned int pk[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) pk[t] = (unsigned int)f2bf(v[2 * t]) | ((unsigned int)f2bf(v[2 * t + 1]) << 16);
+            uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<u16*>(epi.out) + (int64_t)row * epi.ldo + n0);
+            o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        } else if (EPI == EPI_RESID_F32) {
+            float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + n0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 x = o[q];
+                x.x += v[4 * q] * scale[4 * q]; x.y += v[4 * q + 1] * scale[4 * q + 1];
+                x.z += v[4 * q + 2] * scale[4 * q + 2]; x.w += v[4 * q + 3] * scale[4 * q + 3];
+                o[q] = x;
+            }
+        } else if (EPI == EPI_PATCH_F32) {
+            const int b = row / epi.patches_per_crop, p = row - b * epi.patches_per_crop;
+            const int64_t orow = (int64_t)b * epi.tokens_per_crop + 1 + p;
+            float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(epi.out) + orow * epi.ldo + n0);
+            const float4* ps = reinterpret_cast<const float4*>(epi.pos + (int64_t)p * N + n0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 pp = ps[q];
+                o[q] = make_float4(v[4 * q] + pp.x, v[4 * q + 1] + pp.y, v[4 * q + 2] + pp.z, v[4 * q + 3] + pp.w);
+            }
+        } else {
+            float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + n0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
     }
 }
