@@ -12,7 +12,7 @@
 int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
                        int* status, hipStream_t s);
 int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
-                    float* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
+                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
 int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,
                             unsigned char* keep, hipStream_t s);
 
@@ -104,8 +104,8 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
         BatchGrid g;
         st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)radius_feature, (int64_t)64 << 20, &g, s);
         if (st) return st;
-        float* spfh; int* nbr_idx; float* nbr_d2; int* nbr_cnt;
-        IBL_ARENA(spfh, float, (int64_t)n * 33 + 64);
+        unsigned char* spfh; int* nbr_idx; float* nbr_d2; int* nbr_cnt;
+        IBL_ARENA(spfh, unsigned char, (int64_t)n * 36 + 64);
         IBL_ARENA(nbr_idx, int, (int64_t)n * max_nn_feature + 64);
         IBL_ARENA(nbr_d2, float, (int64_t)n * max_nn_feature + 64);
         IBL_ARENA(nbr_cnt, int, n + 64);

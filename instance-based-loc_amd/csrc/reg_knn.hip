@@ -391,7 +391,7 @@ __device__ __forceinline__ int clamp_bin11(int h) { return h < 0 ? 0 : (h >= 11 
 struct SpfhConsumer {
     const float4* normals;   // original order
     const int* order;
-    float* spfh;             // [N][33]
+    unsigned char* spfh_cnt; // [N][36] integer SPFH histograms
     int* nbr_idx;            // [N][K]
     float* nbr_d2;           // [N][K]
     int* nbr_cnt;            // [N]
@@ -427,11 +427,9 @@ struct SpfhConsumer {
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
         wave_lds_sync();
-        if (lane < 33) {
-            float v = 0.0f;
-            if (k > 1) v = (float)((double)hist[lane] * (100.0 / (double)(k - 1)));
-            spfh[(int64_t)qi * 33 + lane] = v;
-        }
+        // SPFH(i)[b] = hist[b] * 100 / (k - 1): only the integer histogram (<= 255 per bin) is stored, 36 bytes per point,
+        // so the FPFH pass gathers 36 B instead of 132 B per neighbour; the fp32 value is rebuilt on the fly
+        if (lane < 36) spfh_cnt[(int64_t)qi * 36 + lane] = lane < 33 ? (unsigned char)hist[lane] : (unsigned char)0;
         if (lane == 0) nbr_cnt[qi] = k;
     }
 };
@@ -499,7 +497,7 @@ __global__ __launch_bounds__(256) void ibl_normals_kernel(BatchGrid g, const flo
 
 __global__ __launch_bounds__(256) void ibl_spfh_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
                                                        const int* __restrict__ seg_off, float radius, float r2, int max_nn,
-                                                       float* __restrict__ spfh, int* __restrict__ nbr_idx, float* __restrict__ nbr_d2,
+                                                       unsigned char* __restrict__ spfh_cnt, int* __restrict__ nbr_idx, float* __restrict__ nbr_d2,
                                                        int* __restrict__ nbr_cnt, int* status) {
     __shared__ WaveLds lds[4];
     const int n = seg_off[g.n_seg];
@@ -507,16 +505,32 @@ __global__ __launch_bounds__(256) void ibl_spfh_kernel(BatchGrid g, const float4
     if (qi >= n) return;
     const int s = seg_of(seg_off, g.n_seg, qi);
     SpfhConsumer cons;
-    cons.normals = normals; cons.order = g.order; cons.spfh = spfh; cons.nbr_idx = nbr_idx; cons.nbr_d2 = nbr_d2;
+    cons.normals = normals; cons.order = g.order; cons.spfh_cnt = spfh_cnt; cons.nbr_idx = nbr_idx; cons.nbr_d2 = nbr_d2;
     cons.nbr_cnt = nbr_cnt; cons.K = max_nn; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
     cons.hist = lds[threadIdx.x >> 6].scratch;
     hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
 }
 
 // FPFH(i) = 100 * sum_k SPFH(k)/d2_k / blocksum + SPFH(i)   (one wave per point, lanes = bins)
-__global__ __launch_bounds__(256) void ibl_fpfh_kernel(const float* __restrict__ spfh, const int* __restrict__ nbr_idx,
+__device__ __forceinline__ float spfh_value(const unsigned char* __restrict__ spfh_cnt, const int* __restrict__ nbr_cnt, int j, int b) {
+    const int kj = nbr_cnt[j];
+    if (kj <= 1) return 0.0f;
+    return (float)((double)spfh_cnt[(int64_t)j * 36 + b] * (100.0 / (double)(kj - 1)));
+}
+
+// Neighbour rows are gathered 64 at a time (one per lane, all loads in flight together) into a per-wave LDS tile;
+// the lanes then switch roles to "one histogram bin each" and walk the tile.  The sum over neighbours keeps the list order.
+struct FpfhTile {
+    unsigned char cnt[64][36];
+    double inc[64];       // 100 / (k_j - 1), or 0 when the neighbour has no SPFH
+    double dist[64];      // d2; <= 0 marks a skipped entry (self or zero distance)
+};
+
+__global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __restrict__ spfh_cnt, const int* __restrict__ nbr_idx,
                                                        const float* __restrict__ nbr_d2, const int* __restrict__ nbr_cnt, int K, int n,
                                                        float* __restrict__ fpfh) {
+    __shared__ FpfhTile tiles[4];
+    FpfhTile& T = tiles[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= n) return;
@@ -524,14 +538,31 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const float* __restrict__
     double acc = 0.0;
     const int b = lane < 33 ? lane : 32;
     if (k > 1) {
-        for (int t = 0; t < k; ++t) {
-            const int j = nbr_idx[(int64_t)qi * K + t];
-            const double dist = (double)nbr_d2[(int64_t)qi * K + t];
-            if (j == qi || dist == 0.0) continue;
-            acc += (double)spfh[(int64_t)j * 33 + b] / dist;
+        for (int t0 = 0; t0 < k; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < k) {
+                const int j = nbr_idx[(int64_t)qi * K + t];
+                const double dist = (double)nbr_d2[(int64_t)qi * K + t];
+                const int kj = nbr_cnt[j];
+                const unsigned int* src = reinterpret_cast<const unsigned int*>(spfh_cnt + (int64_t)j * 36);
+                unsigned int* dst = reinterpret_cast<unsigned int*>(T.cnt[lane]);
+#pragma unroll
+                for (int w = 0; w < 9; ++w) dst[w] = src[w];
+                T.inc[lane] = kj > 1 ? 100.0 / (double)(kj - 1) : 0.0;
+                T.dist[lane] = (j == qi || dist == 0.0) ? -1.0 : dist;
+            }
+            wave_lds_sync();
+            const int m = min(64, k - t0);
+            for (int r = 0; r < m; ++r) {
+                const double dist = T.dist[r];
+                if (dist <= 0.0) continue;
+                const float sp = (float)((double)T.cnt[r][b] * T.inc[r]);
+                acc += (double)sp / dist;
+            }
+            wave_lds_sync();
         }
     }
-    // block sums over bins 0-10, 11-21, 22-32 (sequential in bin order, like the reference loop)
+    // block sums over bins 0-10, 11-21, 22-32
     double sum = 0.0;
     const int blk = b / 11;
     for (int t = 0; t < 11; ++t) sum += __shfl(acc, blk * 11 + t, 64);
@@ -539,7 +570,7 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const float* __restrict__
         float out = 0.0f;
         if (k > 1) {
             const double sc = sum != 0.0 ? 100.0 / sum : 0.0;
-            out = (float)(acc * sc + (double)spfh[(int64_t)qi * 33 + lane]);
+            out = (float)(acc * sc + (double)spfh_value(spfh_cnt, nbr_cnt, qi, lane));
         }
         fpfh[(int64_t)qi * 33 + lane] = out;
     }
@@ -595,8 +626,9 @@ int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off
 }
 
 int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
-                    float* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s) {
+                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s) {
     if (n <= 0) return IBL_OK;
+    if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "fpfh: max_nn %d > 256 (SPFH histograms are stored as bytes)", max_nn);
     void* tok;
     ibl_prof_begin(IBL_PROF_SPFH, 156.0 * (double)n, s, &tok);
     hipLaunchKernelGGL(ibl_spfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, (float)radius,

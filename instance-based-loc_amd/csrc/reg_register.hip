@@ -23,7 +23,7 @@
 int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
                        int* status, hipStream_t s);
 int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
-                    float* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
+                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
 int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
                           int max_nn, float4* grad, int* status, hipStream_t s);
 
@@ -189,7 +189,7 @@ struct RansacState {
 };
 
 __global__ void ibl_ransac_init_kernel(RansacState* __restrict__ st, const int* __restrict__ n_corr, int J, long long max_iter,
-                                       double max_dist) {
+                                       double max_dist, int* __restrict__ active, int* __restrict__ n_active) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= J) return;
     RansacState s;
@@ -197,6 +197,7 @@ __global__ void ibl_ransac_init_kernel(RansacState* __restrict__ st, const int* 
     s.best_fit = 0; s.best_rmse = 0; s.est_k = max_iter; s.next_i = 0; s.walked = 0; s.validated = 0; s.best_inl = 0; s.last_update = -1;
     s.done = (n_corr[j] < 3 || max_dist <= 0) ? 1 : 0;
     st[j] = s;
+    if (!s.done) active[atomicAdd(n_active, 1)] = j;
 }
 
 // packed correspondences: cp[2c] = source point, cp[2c + 1] = target point
@@ -212,18 +213,21 @@ __global__ __launch_bounds__(256) void ibl_pack_corr_kernel(const float4* __rest
     }
 }
 
-// hypothesis -> transform; returns false when a checker rejects it
-__device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned seed_lo, unsigned seed_hi, const float4* __restrict__ cp,
-                                         int nc, double max_dist, double edge_sim, double* T) {
+// hypothesis i: Philox draw of three packed correspondences
+__device__ __forceinline__ void ransac_draw(long long i, unsigned job_id, unsigned seed_lo, unsigned seed_hi, const float4* __restrict__ cp,
+                                            int nc, double* s, double* d) {
     unsigned r[4];
     philox4x32((unsigned)i, job_id, (unsigned)((unsigned long long)i >> 32), 0u, seed_lo, seed_hi, r);
-    double s[9], d[9];
     for (int t = 0; t < 3; ++t) {
         const int pick = (int)(((unsigned long long)r[t] * (unsigned long long)nc) >> 32);
         const float4 ps = cp[2 * pick], pd = cp[2 * pick + 1];
         s[3 * t] = ps.x; s[3 * t + 1] = ps.y; s[3 * t + 2] = ps.z;
         d[3 * t] = pd.x; d[3 * t + 1] = pd.y; d[3 * t + 2] = pd.z;
     }
+}
+
+// CorrespondenceCheckerBasedOnEdgeLength
+__device__ __forceinline__ bool ransac_edge_ok(const double* s, const double* d, double edge_sim) {
     for (int a = 0; a < 3; ++a)
         for (int b = a + 1; b < 3; ++b) {
             const double ds = sqrt((s[3 * a] - s[3 * b]) * (s[3 * a] - s[3 * b]) + (s[3 * a + 1] - s[3 * b + 1]) * (s[3 * a + 1] - s[3 * b + 1]) +
@@ -232,6 +236,11 @@ __device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned 
                                    (d[3 * a + 2] - d[3 * b + 2]) * (d[3 * a + 2] - d[3 * b + 2]));
             if (ds < dt * edge_sim || dt < ds * edge_sim) return false;
         }
+    return true;
+}
+
+// 3-point Kabsch + CorrespondenceCheckerBasedOnDistance
+__device__ inline bool ransac_fit_ok(const double* s, const double* d, double max_dist, double* T) {
     double sm[3] = {0, 0, 0}, dm[3] = {0, 0, 0};
     for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) { sm[a] += s[3 * t + a]; dm[a] += d[3 * t + a]; }
     for (int a = 0; a < 3; ++a) { sm[a] /= 3; dm[a] /= 3; }
@@ -248,34 +257,77 @@ __device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned 
     return true;
 }
 
-// grid (round / 256, J)
+__device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned seed_lo, unsigned seed_hi, const float4* __restrict__ cp,
+                                         int nc, double max_dist, double edge_sim, double* T) {
+    double s[9], d[9];
+    ransac_draw(i, job_id, seed_lo, seed_hi, cp, nc, s, d);
+    if (!ransac_edge_ok(s, d, edge_sim)) return false;
+    return ransac_fit_ok(s, d, max_dist, T);
+}
+
+// grid (round / 4096, active jobs): each block walks 4096 consecutive hypotheses.  The cheap part (draw + edge-length
+// check, ~99 % rejected) runs on every lane; the survivors are compacted through LDS so that the expensive part
+// (fp64 Kabsch + distance check) runs on densely packed lanes.  `flags` is zeroed by the host before the launch.
+#define RANSAC_CHUNK 4096
 __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
                                                               long long max_iter, double max_dist, double edge_sim, unsigned seed_lo,
                                                               unsigned seed_hi, unsigned job_id_base, int round_size,
                                                               unsigned char* __restrict__ flags /* [J][round] */,
-                                                              int* __restrict__ blk_cnt /* [J][round/256] */) {
-    const int j = blockIdx.y;
+                                                              int* __restrict__ blk_cnt /* [J][round/256] */,
+                                                              const int* __restrict__ active /* job ids still running */) {
+    const int j = active[blockIdx.y];
     const int nblk = round_size / 256;
     const RansacState& S = st[j];
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    const long long i = S.next_i + slot;
-    bool ok = false;
-    if (!S.done && i < S.est_k && i < max_iter) {
-        double T[16];
-        ok = ransac_hypothesis(i, job_id_base + (unsigned)j, seed_lo, seed_hi, cp + 2 * (int64_t)job_off[j], n_corr[j], max_dist, edge_sim, T);
+    const long long next_i = S.next_i, est_k = S.est_k;
+    const bool job_on = !S.done;
+    const float4* c = cp + 2 * (int64_t)job_off[j];
+    const int nc = n_corr[j];
+    const unsigned job_id = job_id_base + (unsigned)j;
+    __shared__ int surv[1024];
+    __shared__ int nsurv;
+    __shared__ int cnt16[16];
+    if (threadIdx.x < 16) cnt16[threadIdx.x] = 0;
+    const int lane = threadIdx.x & 63;
+    for (int sub = 0; sub < 4; ++sub) {
+        __syncthreads();
+        if (threadIdx.x == 0) nsurv = 0;
+        __syncthreads();
+        for (int r = 0; r < 4; ++r) {
+            const int slot = blockIdx.x * RANSAC_CHUNK + sub * 1024 + r * 256 + threadIdx.x;
+            const long long i = next_i + slot;
+            bool ok = false;
+            if (job_on && i < est_k && i < max_iter) {
+                double sp[9], dp[9];
+                ransac_draw(i, job_id, seed_lo, seed_hi, c, nc, sp, dp);
+                ok = ransac_edge_ok(sp, dp, edge_sim);
+            }
+            const unsigned long long m = __ballot(ok);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&nsurv, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (ok) surv[base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+        }
+        __syncthreads();
+        const int ns = nsurv;
+        for (int t = threadIdx.x; t < ns; t += 256) {
+            const int slot = surv[t];
+            double sp[9], dp[9], T[16];
+            ransac_draw(next_i + slot, job_id, seed_lo, seed_hi, c, nc, sp, dp);
+            if (ransac_fit_ok(sp, dp, max_dist, T)) {
+                flags[(int64_t)j * round_size + slot] = 1;
+                atomicAdd(&cnt16[(slot - blockIdx.x * RANSAC_CHUNK) >> 8], 1);
+            }
+        }
     }
-    flags[(int64_t)j * round_size + slot] = ok ? 1 : 0;
-    __shared__ int wc[4];
-    const unsigned long long m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) blk_cnt[j * nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+    if (threadIdx.x < 16) blk_cnt[j * nblk + blockIdx.x * 16 + threadIdx.x] = cnt16[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned char* __restrict__ flags, const int* __restrict__ blk_off,
-                                                                 int round_size, int* __restrict__ list /* slot ids, ordered */) {
-    const int j = blockIdx.y;
+                                                                 int round_size, int* __restrict__ list /* slot ids, ordered */,
+                                                                 const int* __restrict__ active) {
+    const int j = active[blockIdx.y];
     const int nblk = round_size / 256;
     const int slot = blockIdx.x * 256 + threadIdx.x;
     const bool ok = flags[(int64_t)j * round_size + slot] != 0;
@@ -334,8 +386,9 @@ __global__ __launch_bounds__(64) void ibl_ransac_fold_kernel(RansacState* __rest
                                                              long long max_iter, double confidence, int round_size,
                                                              const int* __restrict__ blk_off, const int* __restrict__ list,
                                                              const int* __restrict__ e_inl, const double* __restrict__ e_err2,
-                                                             const double* __restrict__ e_T, int total, int* __restrict__ n_active) {
-    const int j = blockIdx.x;
+                                                             const double* __restrict__ e_T, int total, int* __restrict__ n_active,
+                                                             const int* __restrict__ active, int* __restrict__ active_next) {
+    const int j = active[blockIdx.x];
     const int lane = threadIdx.x;
     RansacState S = st[j];
     if (S.done) return;
@@ -389,7 +442,7 @@ __global__ __launch_bounds__(64) void ibl_ransac_fold_kernel(RansacState* __rest
     for (int t = 0; t < 12; ++t) { const double v = __shfl(bt, t, 64); if (lane == 0) S.best_T[t] = v; }
     if (lane == 0) {
         st[j] = S;
-        if (!S.done) atomicAdd(n_active, 1);
+        if (!S.done) active_next[atomicAdd(n_active, 1)] = j;     // order irrelevant: all per-round tables are indexed by job id
     }
 }
 
@@ -667,8 +720,8 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
             BatchGrid gB;
             st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(voxel_size * 5), (int64_t)64 << 20, &gB, s);
             if (st) return st;
-            float *spfh, *fpfh, *nbr_d2; int *nbr_idx, *nbr_cnt, *nn;
-            IBL_ARENA(spfh, float, (int64_t)N * 33 + 64);
+            unsigned char* spfh; float *fpfh, *nbr_d2; int *nbr_idx, *nbr_cnt, *nn;
+            IBL_ARENA(spfh, unsigned char, (int64_t)N * 36 + 64);
             IBL_ARENA(fpfh, float, (int64_t)N * 33 + 64);
             IBL_ARENA(nbr_idx, int, (int64_t)N * 100 + 64);
             IBL_ARENA(nbr_d2, float, (int64_t)N * 100 + 64);
@@ -707,37 +760,47 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
             IBL_ARENA(tmp, unsigned char, (int64_t)tmp_bytes + 256);
             hipLaunchKernelGGL(ibl_pack_corr_kernel, dim3(16, J), dim3(256), 0, s, P, d_job_off, J, corr, n_corr, cp);
             IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist);
+            int* active[2];
+            IBL_ARENA(active[0], int, J + 1);
+            IBL_ARENA(active[1], int, J + 1);
+            IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
+            hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist,
+                               active[0], n_active);
             IBL_LAUNCH_CHECK();
+            int h_active = 0;
+            IBL_HIP_CHECK(hipMemcpyAsync(&h_active, n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+            IBL_HIP_CHECK(hipStreamSynchronize(s));
             long long walked = 0;
             int round_size = RANSAC_FIRST_ROUND;
-            while (walked < ransac_max_iter) {
+            int cur = 0;
+            while (walked < ransac_max_iter && h_active > 0) {
                 const int nblk = round_size / 256;
-                hipLaunchKernelGGL(ibl_ransac_flag_kernel, dim3(nblk, J), dim3(256), 0, s, rs, cp, d_job_off, n_corr, (long long)ransac_max_iter,
-                                   max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags, blk_cnt);
+                // per-round tables are indexed by job id; jobs that are not launched must read as "no survivors"
+                IBL_HIP_CHECK(hipMemsetAsync(blk_cnt, 0, sizeof(int) * ((size_t)J * nblk + 1), s));
+                IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)J * round_size, s));
+                hipLaunchKernelGGL(ibl_ransac_flag_kernel, dim3(round_size / RANSAC_CHUNK, h_active), dim3(256), 0, s, rs, cp, d_job_off, n_corr, (long long)ransac_max_iter,
+                                   max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags, blk_cnt, active[cur]);
                 IBL_LAUNCH_CHECK();
-                IBL_HIP_CHECK(hipMemsetAsync(blk_cnt + (int64_t)J * nblk, 0, sizeof(int), s));
                 IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, J * nblk + 1, s));
                 int total = 0;
                 IBL_HIP_CHECK(hipMemcpyAsync(&total, blk_off + (int64_t)J * nblk, sizeof(int), hipMemcpyDeviceToHost, s));
                 IBL_HIP_CHECK(hipStreamSynchronize(s));
                 if (total > list_cap) return ibl_set_error(IBL_ERR_OVERFLOW, "ransac: %d surviving hypotheses in one round exceed the list capacity %d", total, list_cap);
                 if (total > 0) {
-                    hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, J), dim3(256), 0, s, flags, blk_off, round_size, list);
+                    hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, h_active), dim3(256), 0, s, flags, blk_off, round_size, list, active[cur]);
                     IBL_LAUNCH_CHECK();
                     hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3((total + 3) / 4), dim3(256), 0, s, rs, cp, d_job_off, n_corr, J, max_dist, 0.9,
                                        (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total, e_inl, e_err2, e_T);
                     IBL_LAUNCH_CHECK();
                 }
                 IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
-                hipLaunchKernelGGL(ibl_ransac_fold_kernel, dim3(J), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99, round_size,
-                                   blk_off, list, e_inl, e_err2, e_T, total, n_active);
+                hipLaunchKernelGGL(ibl_ransac_fold_kernel, dim3(h_active), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99, round_size,
+                                   blk_off, list, e_inl, e_err2, e_T, total, n_active, active[cur], active[cur ^ 1]);
                 IBL_LAUNCH_CHECK();
-                int h_active = 0;
                 IBL_HIP_CHECK(hipMemcpyAsync(&h_active, n_active, sizeof(int), hipMemcpyDeviceToHost, s));
                 IBL_HIP_CHECK(hipStreamSynchronize(s));
+                cur ^= 1;
                 walked += round_size;
-                if (h_active == 0) break;
                 if (round_size < max_round) round_size = std::min(max_round, round_size * 8);
             }
         }
