@@ -32,6 +32,8 @@ struct WaveLds {
     int b_idx[KNN_CAPB];
     int b_j[KNN_CAPB];
     int scratch[64];
+    int sel_j[256];          // consumers that do heavy per-neighbour work first compact the selected set here
+    float sel_d2[256];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -391,6 +393,7 @@ __device__ __forceinline__ int clamp_bin11(int h) { return h < 0 ? 0 : (h >= 11 
 struct SpfhConsumer {
     const float4* normals;   // original order
     const int* order;
+    const float4* sorted;    // cell-sorted points
     unsigned char* spfh_cnt; // [N][36] integer SPFH histograms
     int* nbr_idx;            // [N][K]
     float* nbr_d2;           // [N][K]
@@ -398,34 +401,43 @@ struct SpfhConsumer {
     int K;
     int qi;
     float4 q, qn;
-    int* hist;               // per-wave LDS, 33 ints
+    WaveLds* L;
     int ncount;
     __device__ void begin(int) {
         const int lane = threadIdx.x & 63;
-        if (lane < 33) hist[lane] = 0;
+        if (lane < 33) L->scratch[lane] = 0;
         ncount = 0;
         wave_lds_sync();
     }
-    __device__ void accept(bool sel, int j, const float4& p, float d2) {
+    // selected candidates are only appended to the per-wave list here; the pair features (fp64, ~300 instructions)
+    // are computed afterwards on densely packed lanes
+    __device__ void accept(bool sel, int j, const float4&, float d2) {
         const int lane = threadIdx.x & 63;
         const unsigned long long m = __ballot(sel);
         if (sel) {
-            const int jo = order[j];
             const int pos = ncount + __popcll(m & ((1ull << lane) - 1ull));
-            nbr_idx[(int64_t)qi * K + pos] = jo;
-            nbr_d2[(int64_t)qi * K + pos] = d2;
-            if (jo != qi) {
-                double f[3];
-                pair_features_d(q, qn, p, normals[jo], f);
-                atomicAdd(&hist[clamp_bin11((int)floor(11 * (f[0] + M_PI) / (2.0 * M_PI)))], 1);
-                atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
-                atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
-            }
+            L->sel_j[pos] = j;
+            L->sel_d2[pos] = d2;
         }
         ncount += __popcll(m);
     }
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
+        int* hist = L->scratch;
+        wave_lds_sync();
+        for (int t = lane; t < k; t += 64) {
+            const int j = L->sel_j[t];
+            const int jo = order[j];
+            nbr_idx[(int64_t)qi * K + t] = jo;
+            nbr_d2[(int64_t)qi * K + t] = L->sel_d2[t];
+            if (jo != qi) {
+                double f[3];
+                pair_features_d(q, qn, sorted[j], normals[jo], f);
+                atomicAdd(&hist[clamp_bin11((int)floor(11 * (f[0] + M_PI) / (2.0 * M_PI)))], 1);
+                atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
+                atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
+            }
+        }
         wave_lds_sync();
         // SPFH(i)[b] = hist[b] * 100 / (k - 1): only the integer histogram (<= 255 per bin) is stored, 36 bytes per point,
         // so the FPFH pass gathers 36 B instead of 132 B per neighbour; the fp32 value is rebuilt on the fly
@@ -437,14 +449,28 @@ struct SpfhConsumer {
 struct GradConsumer {
     const float4* normals;
     const int* order;
-    const float4* pts;       // original order (for intensity of neighbours use sorted p.w)
+    const float4* sorted;
     float4* grad;
     int qi;
     float4 q, qn;
-    double a[9];             // AtA (6 unique: 00 01 02 11 12 22) + Atb (3)
-    __device__ void begin(int) { for (int t = 0; t < 9; ++t) a[t] = 0.0; }
-    __device__ void accept(bool sel, int j, const float4& p, float) {
-        if (sel && order[j] != qi) {
+    WaveLds* L;
+    int ncount;
+    __device__ void begin(int) { ncount = 0; }
+    __device__ void accept(bool sel, int j, const float4&, float) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long m = __ballot(sel);
+        if (sel) L->sel_j[ncount + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        ncount += __popcll(m);
+    }
+    __device__ void finish(int k) {
+        const int lane = threadIdx.x & 63;
+        wave_lds_sync();
+        double a[9];             // AtA (6 unique: 00 01 02 11 12 22) + Atb (3)
+        for (int t = 0; t < 9; ++t) a[t] = 0.0;
+        for (int t = lane; t < k; t += 64) {
+            const int j = L->sel_j[t];
+            if (order[j] == qi) continue;
+            const float4 p = sorted[j];
             const double vt[3] = {q.x, q.y, q.z}, nt[3] = {qn.x, qn.y, qn.z};
             const double dd[3] = {(double)p.x - vt[0], (double)p.y - vt[1], (double)p.z - vt[2]};
             const double pr = dot3d(dd, nt);
@@ -453,10 +479,8 @@ struct GradConsumer {
             a[0] += r[0] * r[0]; a[1] += r[0] * r[1]; a[2] += r[0] * r[2]; a[3] += r[1] * r[1]; a[4] += r[1] * r[2]; a[5] += r[2] * r[2];
             a[6] += r[0] * b; a[7] += r[1] * b; a[8] += r[2] * b;
         }
-    }
-    __device__ void finish(int k) {
         for (int t = 0; t < 9; ++t) a[t] = wave_sum_d(a[t]);
-        if ((threadIdx.x & 63) == 0) {
+        if (lane == 0) {
             double gx[3] = {0, 0, 0};
             if (k >= 4) {
                 const double nt[3] = {qn.x, qn.y, qn.z};
@@ -507,7 +531,7 @@ __global__ __launch_bounds__(256) void ibl_spfh_kernel(BatchGrid g, const float4
     SpfhConsumer cons;
     cons.normals = normals; cons.order = g.order; cons.spfh_cnt = spfh_cnt; cons.nbr_idx = nbr_idx; cons.nbr_d2 = nbr_d2;
     cons.nbr_cnt = nbr_cnt; cons.K = max_nn; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
-    cons.hist = lds[threadIdx.x >> 6].scratch;
+    cons.L = &lds[threadIdx.x >> 6]; cons.sorted = g.sorted_pts;
     hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
 }
 
@@ -584,7 +608,8 @@ __global__ __launch_bounds__(256) void ibl_color_grad_kernel(BatchGrid g, const 
     if (qi >= q1) return;
     const int s = seg_of(seg_off, g.n_seg, qi);
     GradConsumer cons;
-    cons.normals = normals; cons.order = g.order; cons.pts = pts; cons.grad = grad; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
+    cons.normals = normals; cons.order = g.order; cons.sorted = g.sorted_pts; cons.grad = grad; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
+    cons.L = &lds[threadIdx.x >> 6];
     hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
 }
 
@@ -643,6 +668,7 @@ int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals
 int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
                           int max_nn, float4* grad, int* status, hipStream_t s) {
     if (q1 <= q0) return IBL_OK;
+    if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "colour gradient: max_nn %d > 256", max_nn);
     hipLaunchKernelGGL(ibl_color_grad_kernel, dim3((q1 - q0 + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, q0, q1, (float)radius,
                        (float)(radius * radius), max_nn, grad, status);
     IBL_LAUNCH_CHECK();
