@@ -474,9 +474,16 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
     int best = -1;
     float bd = r2;
     const int x0 = max(cx - reach, 0), x1 = min(cx + reach, sg.nx - 1);
+    const float csz = 1.0f / sg.inv, slack = 1e-4f * csz + 1e-6f;
     if (x1 >= x0)
-        for (int z = max(cz - reach, 0); z <= min(cz + reach, sg.nz - 1); ++z)
+        for (int z = max(cz - reach, 0); z <= min(cz + reach, sg.nz - 1); ++z) {
+            // lower bound of the distance to any point of the row / cell: skip what cannot beat the current best
+            const float zlo = sg.minz + (float)z * csz;
+            const float gz = fmaxf((qz < zlo ? zlo - qz : (qz > zlo + csz ? qz - zlo - csz : 0.0f)) - slack, 0.0f);
             for (int y = max(cy - reach, 0); y <= min(cy + reach, sg.ny - 1); ++y) {
+                const float ylo = sg.miny + (float)y * csz;
+                const float gy = fmaxf((qy < ylo ? ylo - qy : (qy > ylo + csz ? qy - ylo - csz : 0.0f)) - slack, 0.0f);
+                if (gz * gz + gy * gy >= bd) continue;
                 const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
                 const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
                 for (int jj = b; jj < e; ++jj) {
@@ -486,6 +493,7 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
                     else if (d2 == bd && best >= 0) { const int o = g.order[jj]; if (o < best) best = o; }
                 }
             }
+        }
     *d2out = bd;
     return best;
 }
