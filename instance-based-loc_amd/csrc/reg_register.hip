@@ -119,9 +119,18 @@ __global__ __launch_bounds__(256) void ibl_feat_nn_kernel(const float* __restric
         for (int x = threadIdx.x; x < nt * 33; x += 256) tile[x] = feat[(int64_t)t0 * 33 + x];
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
+            // the partial sums of the chain are non-decreasing, so a target is abandoned as soon as no lane of the wave can
+            // still beat its running minimum (checked after each of the three 11-bin histogram blocks); the surviving
+            // distances are the complete k = 0..32 chains, bit-identical to the unpruned form
             float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 33; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
+            for (int k = 0; k < 11; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
+            if (__ballot(acc < best) == 0ull) continue;
+#pragma unroll
+            for (int k = 11; k < 22; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
+            if (__ballot(acc < best) == 0ull) continue;
+#pragma unroll
+            for (int k = 22; k < 33; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
             if (acc < best) { best = acc; bj = t0 - db + t; }
         }
     }
