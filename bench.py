@@ -232,8 +232,9 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16 (ViT MFMA) / f32+f64 (match, registration)",
             "data": "synthetic",
-            "config": {"workload": "C2: DINOv2 ViT-B/14 crops 224^2 (Q=7), 1k-instance memory (E=4), FPFH+RANSAC+coloured ICP "
-                       "on 5k-pt clouds, whole-memory evaluate", "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
+            "config": {"workload": f"{'C2' if args.memory == 1000 else 'T' if args.memory == 10000 else 'custom'}: {args.model} crops 224^2 "
+                       f"(Q={args.q}), {args.memory}-instance memory (E={args.views}), FPFH+RANSAC+coloured ICP on {args.points}-pt clouds, "
+                       "whole-memory evaluate", "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
                        "points_per_object": args.points, "model": args.model, "parallelism": f"frames-dp{world_size}"},
             "roofline": roof,
             "cpu_baseline": cpu,
