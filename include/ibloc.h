@@ -122,6 +122,37 @@ int ibl_vit_forward(const ibl_vit_desc* desc, const ibl_vit_weights* weights, co
                     float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* DATOR RGB-D encoder                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Fusion-head weights of build_FourDNet (dator/model/make_model.py:484-591), all [dev] fp32.  Linear weights are
+ * [out][in] row-major; hyper-network convolution weights are repacked to [9 taps][in][out]. */
+typedef struct {
+    const float *proj_local_rgb_w, *proj_local_rgb_b, *proj_global_rgb_w, *proj_global_rgb_b, *merge_rgb_w, *merge_rgb_b;
+    const float *proj_local_depth_w, *proj_local_depth_b, *proj_global_depth_w, *proj_global_depth_b, *merge_depth_w, *merge_depth_b;
+    const float *Q_r_w, *Q_r_b, *V_r_w, *V_r_b, *Q_d_w, *Q_d_b, *V_d_w, *V_d_b;
+    const float *r2r_sel_w, *r2r_sel_b, *r2r_aw_w, *r2r_aw_b, *r2r_ffn_w, *r2r_ffn_b, *r2r_norm_g, *r2r_norm_b;
+    const float *d2d_sel_w, *d2d_sel_b, *d2d_aw_w, *d2d_aw_b, *d2d_ffn_w, *d2d_ffn_b, *d2d_norm_g, *d2d_norm_b;
+    const float *d2r_sel_w, *d2r_sel_b, *d2r_aw_w, *d2r_aw_b, *d2r_ffn_w, *d2r_ffn_b, *d2r_norm_g, *d2r_norm_b;
+    const float *r2d_sel_w, *r2d_sel_b, *r2d_aw_w, *r2d_aw_b, *r2d_ffn_w, *r2d_ffn_b, *r2d_norm_g, *r2d_norm_b;
+    const float *hyper0_w, *hyper0_b, *hyper1_w, *hyper1_b, *hyper2_w, *hyper2_b, *hyper3_w, *hyper3_b;
+} ibl_dator_head_weights;
+
+/* build_FourDNet.forward after the two backbones (dator/model/make_model.py:676-843, eval mode):
+ * rgb_tokens / depth_tokens [dev] fp32 [batch][129][768] (ibl_vit_forward with IBL_VIT_OUT_ALL_TOKENS on the TransReID
+ * streams, 11 of 12 blocks, no final norm) -> out [dev] fp32 [batch][128].  Replaces get_dator_embeddings
+ * (utils/embeddings.py:105-121) together with ibl_preprocess_crops / ibl_preprocess_depth. */
+int64_t ibl_dator_head_workspace_bytes(int batch);
+int ibl_dator_head_forward(const ibl_dator_head_weights* w, const float* rgb_tokens, const float* depth_tokens, int batch,
+                           float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Depth crops (float, [dev], crop i = sizes[2i] x sizes[2i+1] floats at src + offsets[i]) -> bf16 patch matrix of the
+ * depth stream: bilinear resize to out_h x out_w (cv2.INTER_LINEAR convention), clip [dmin, dmax], (d - dmin)/(dmax - dmin),
+ * (x - 0.5)/0.5, three identical channels (dator/get_embeds.py:129-136; the reference's dator_wrapper is missing). */
+int ibl_preprocess_depth(const float* src, const int64_t* offsets, const int32_t* sizes, int n_crops, int out_h, int out_w,
+                         int patch, int patch_k_pad, float dmin, float dmax, void* patches, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* match: L2 normalisation + closest-similarity matrix                 */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -9,7 +9,7 @@ their names and `(**kwargs) -> torch.Tensor` signature:
     get_all_clip_embeddings   :31-50   L2-normalised 512-d
     get_all_dino_embeddings   :53-71   CLS after the final LayerNorm, 768-d, un-normalised
     get_all_vit_embeddings    :74-98   CLS, 768-d
-    get_dator_embeddings      :105-121 RGB-D 128-d (not built in this round; raises)
+    get_dator_embeddings      :105-121 RGB-D 128-d (ibloc_amd.dator.DatorEncoder registered as kind "dator")
 
 `embed_batch(kind, crops)` is the batched form the localisation engine uses (one launch sequence for many crops).
 """
@@ -123,6 +123,8 @@ def get_all_vit_embeddings(**kwargs) -> torch.Tensor:
 
 
 def get_dator_embeddings(**kwargs) -> torch.Tensor:
-    raise NotImplementedError(
-        "the DATOR RGB-D dual-stream encoder (dator/model/make_model.py:629-843) is the next hot-path row (DESIGN.md); "
-        "its TransReID streams already run on VitEncoder (IBL_VIT_OUT_ALL_TOKENS), the fusion head is not built yet")
+    """utils/embeddings.py:105-121: crop the full depth image with the bounding box (xyxy), embed (RGB crop, depth crop)."""
+    enc = _encoder("dator")
+    bb = kwargs["current_obj_bounding_box"]
+    depth = kwargs["full_depth_image"][int(bb[1]):int(bb[3]), int(bb[0]):int(bb[2])]
+    return enc.embed([kwargs["current_obj_grounded_img"]], [np.asarray(depth, dtype=np.float32)])[0]

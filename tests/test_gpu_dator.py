@@ -1,0 +1,74 @@
+"""-m gpu: DATOR (two TransReID streams on the shared bf16 ViT kernels + fp32 fusion head) vs the torch oracle, which is
+itself pinned to the reference's build_FourDNet (tests/golden/dator_golden.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dator_oracle as do
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dator_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def enc():
+    from ibloc_amd import dator as D
+    rw, dw, hw = D.random_stream_weights(301), D.random_stream_weights(302), D.random_head_weights(303)
+    return D.DatorEncoder(rw, dw, hw), (rw, dw, hw)
+
+
+def test_head_fp32_vs_oracle(enc):
+    """the fusion head alone, fed with the oracle's fp32 tokens: tight tolerance (fp32 kernels)"""
+    from ibloc_amd import dator as D
+    e, (rw, dw, hw) = enc
+    rng = np.random.default_rng(304)
+    rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
+    depth = np.repeat(rng.uniform(-1, 1, size=(3, 1, 256, 128)).astype(np.float32), 3, axis=1)
+    rt, dt = do.stream_tokens(rw, D.STREAM_CFG, rgb), do.stream_tokens(dw, D.STREAM_CFG, depth)
+    got = e.head(torch.from_numpy(rt).cuda(), torch.from_numpy(dt).cuda()).cpu().numpy()
+    exp = do.head_forward(hw, rt, dt)
+    assert np.abs(got - exp).max() < 1e-4 * max(1.0, np.abs(exp).max())
+    assert np.abs(exp - GOLD["embedding"]).max() < 2e-4 * max(1.0, np.abs(GOLD["embedding"]).max())
+
+
+def test_full_forward_vs_oracle_and_reference_golden(enc):
+    """pixels -> embedding through the bf16 streams: rel-L2 <= 2e-2, cosine >= 0.9995 (same bar as the other encoders)"""
+    e, _ = enc
+    rng = np.random.default_rng(304)
+    rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
+    depth = np.repeat(rng.uniform(-1, 1, size=(3, 1, 256, 128)).astype(np.float32), 3, axis=1)
+    got = e.forward_pixels(torch.from_numpy(rgb), torch.from_numpy(depth)).cpu().numpy()
+    ref = GOLD["embedding"]
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    cos = np.min(np.sum(got * ref, -1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(ref, axis=-1)))
+    print("dator rel_l2", rel, "cos", cos)
+    assert rel <= 2e-2 and cos >= 0.9995
+
+
+def test_preprocess_and_facade(enc):
+    from ibloc_amd import dator as D
+    from ibloc_amd.utils import embeddings as emb
+    e, (rw, dw, hw) = enc
+    rng = np.random.default_rng(7)
+    crops = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in [(90, 60), (256, 128), (300, 111)]]
+    depths = [rng.uniform(0.3, 8.0, size=(c.shape[0], c.shape[1])).astype(np.float32) for c in crops]
+    # depth patches vs the oracle's restatement of get_embeds.py:129-136
+    pd = e.preprocess_depth(depths)
+    exp_px = np.stack([do.preprocess_depth(d) for d in depths])
+    exp_p = e.depth.patches_from_pixels(torch.from_numpy(exp_px)).float().cpu().numpy()
+    assert np.abs(pd.float().cpu().numpy() - exp_p).max() <= 2 ** -7        # one bf16 step at |x| <= 1
+    got = e.embed(crops, depths).cpu().numpy()
+    exp = do.forward(rw, dw, hw, D.STREAM_CFG, np.stack([do.preprocess_rgb(c) for c in crops]), exp_px)
+    rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
+    assert rel <= 2e-2
+    # the reference-shaped entry point: bbox crop of the full depth image
+    emb.set_encoder("dator", e)
+    full_depth = rng.uniform(0.3, 8.0, size=(200, 240)).astype(np.float32)
+    bb = torch.tensor([20.0, 30.0, 110.0, 150.0])
+    out = emb.get_dator_embeddings(current_obj_grounded_img=crops[0], current_obj_bounding_box=bb, full_depth_image=full_depth,
+                                   device="cuda")
+    assert out.shape == (128,)
+    exp1 = do.forward(rw, dw, hw, D.STREAM_CFG, do.preprocess_rgb(crops[0])[None], do.preprocess_depth(full_depth[30:150, 20:110])[None])[0]
+    assert np.linalg.norm(out.cpu().numpy() - exp1) / np.linalg.norm(exp1) <= 2e-2

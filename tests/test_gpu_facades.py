@@ -62,8 +62,9 @@ def test_embeddings_facade():
     emb.set_encoder("clip", V.VitEncoder(ccfg, cw))
     c = emb.get_all_clip_embeddings(current_obj_grounded_img=crop)
     assert abs(float(c.norm()) - 1.0) < 1e-5                           # L2-normalised like the reference (:48)
-    with pytest.raises(NotImplementedError):
-        emb.get_dator_embeddings(current_obj_grounded_img=crop)
+    emb._ENCODERS.pop("dator", None)
+    with pytest.raises(RuntimeError):
+        emb.get_dator_embeddings(current_obj_grounded_img=crop, current_obj_bounding_box=[0, 0, 4, 4], full_depth_image=np.ones((8, 8), np.float32))
 
 
 def test_object_memory_localise_with_stub_finder(tmp_path):
