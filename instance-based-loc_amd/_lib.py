@@ -5,6 +5,11 @@ there is no CPU fallback."""
 import ctypes as C
 import os
 
+# torch first: its wheel bundles the HIP runtime (libamdhip64 / libhsa-runtime64) that owns the process's device state.
+# Loading libibloc_hip.so before torch would pull a second runtime from /opt/rocm into the process and every launch
+# from this library would then fail with hipErrorNoDevice.
+import torch  # noqa: F401  (device memory and streams are torch's; see DESIGN.md "boundary")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libibloc_hip.so")
 

@@ -48,7 +48,7 @@ struct GemmEpi {
     int patches_per_crop;   // P (EPI_PATCH)
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int GBK = 64;
 constexpr int LDS_ROW = GBK * 2;        // 128-byte tile rows, XOR-swizzled 16-byte chunks (no padding)
 
 // LDS images: a tile row holds 8 chunks of 16 bytes; chunk c of row r lives at chunk c ^ key(r).
@@ -57,21 +57,29 @@ constexpr int LDS_ROW = GBK * 2;        // 128-byte tile rows, XOR-swizzled 16-b
 __device__ __forceinline__ int key_act(int r) { return r & 7; }
 __device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
-// C[M][N] = A[M][K] * W[N][K]^T.  The MFMA computes the TRANSPOSED tile (W is the A operand, the activations
-// the B operand) and MFMA row 4*fg + r of n-tile j is mapped to weight row 16*fg + 4*j + r, so that every lane
-// ends up with 16 CONSECUTIVE output columns of one output row: the epilogue is 16-byte vector stores.
-template <int EPI>
-__global__ __launch_bounds__(256) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
-                                                        int64_t ldw, int M, int N, int K, GemmEpi epi) {
+// C[M][N] = A[M][K] * W[N][K]^T.  Block tile (WM * MI * 16) x (WN * 64), one wave per (MI * 16) x 64 sub-tile:
+//   <MI = 4, WM = 2, WN = 2>: 128 x 128, 256 threads, 64 KiB LDS (2 blocks / CU)  -- any N % 128 == 0
+//   <MI = 8, WM = 2, WN = 4>: 256 x 256, 512 threads, 128 KiB LDS (1 block / CU) -- N % 256 == 0; halves the operand
+//                             traffic per FLOP (the 128 x 128 form saturates the L2 path at ~7 TB/s)
+// The MFMA computes the TRANSPOSED tile (W is the A operand, the activations the B operand) and MFMA row 4*fg + r of
+// n-tile j is mapped to weight row 16*fg + 4*j + r, so that every lane ends up with 16 CONSECUTIVE output columns of one
+// output row: the epilogue is 16-byte vector stores.  Operand tiles are staged with direct-to-LDS loads
+// (global_load_lds_dwordx4): one wave instruction writes 1 KiB = 8 tile rows linearly, so the XOR swizzle is applied
+// to the per-lane SOURCE address.
+template <int EPI, int MI, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
+                                                                  int64_t ldw, int M, int N, int K, GemmEpi epi) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64, NW = WM * WN;
+    constexpr int A_BYTES = BM * LDS_ROW, W_BYTES = BN * LDS_ROW, STAGE = A_BYTES + W_BYTES;
+    constexpr int GA = BM / 8 / NW, GW = BN / 8 / NW;       // 8-row groups (1 KiB wave instructions) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // buffer b: activation tile at (2b) * GBM * LDS_ROW, weight tile at (2b + 1) * GBM * LDS_ROW
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // XCD-aware remap: consecutive tiles along N (sharing the A panel) stay on one XCD's L2
-    const int nbn = N / GBN;
-    const int nbm = (M + GBM - 1) / GBM;
+    const int nbn = N / BN;
+    const int nbm = (M + BM - 1) / BM;
     const int nwg = nbn * nbm;
     int bid = blockIdx.x;
     {
@@ -79,93 +87,72 @@ __global__ __launch_bounds__(256) void ibl_gemm_bf16_tn(const u16* __restrict__ 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
     const int bm = bid / nbn, bn = bid % nbn;
-    const int row0 = bm * GBM, col0 = bn * GBN;
+    const int row0 = bm * BM, col0 = bn * BN;
 
-    // staging: 1024 16-byte chunks per operand tile, 4 per thread
-    int st_a[4], st_w[4];
-    const u16* a_src[4];
-    const u16* w_src[4];
+    const u16* a_src[GA];
+    const u16* w_src[GW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        const int r = c >> 3, ch = c & 7;
-        st_a[i] = r * LDS_ROW + ((ch ^ key_act(r)) << 4);
-        st_w[i] = r * LDS_ROW + ((ch ^ key_w(r)) << 4);
+    for (int i = 0; i < GA; ++i) {
+        const int r = (wave + NW * i) * 8 + (lane >> 3), pch = lane & 7;
         int ar = row0 + r;
         if (ar >= M) ar = M - 1;
-        a_src[i] = A + (int64_t)ar * lda + ch * 8;
-        w_src[i] = W + (int64_t)(col0 + r) * ldw + ch * 8;
+        a_src[i] = A + (int64_t)ar * lda + ((pch ^ key_act(r)) << 3);
     }
-    // register staging of the next K tile (kept in named registers: a lambda / array-by-reference form is demoted
-    // to scratch memory by hipcc, which serialises every load behind a scratch store)
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GEMM_GLOAD(kt)                                                             \
-    do {                                                                           \
-        const int64_t _ko = (int64_t)(kt) * GBK;                                   \
-        ra0 = *reinterpret_cast<const uint4*>(a_src[0] + _ko);                     \
-        ra1 = *reinterpret_cast<const uint4*>(a_src[1] + _ko);                     \
-        ra2 = *reinterpret_cast<const uint4*>(a_src[2] + _ko);                     \
-        ra3 = *reinterpret_cast<const uint4*>(a_src[3] + _ko);                     \
-        rb0 = *reinterpret_cast<const uint4*>(w_src[0] + _ko);                     \
-        rb1 = *reinterpret_cast<const uint4*>(w_src[1] + _ko);                     \
-        rb2 = *reinterpret_cast<const uint4*>(w_src[2] + _ko);                     \
-        rb3 = *reinterpret_cast<const uint4*>(w_src[3] + _ko);                     \
-    } while (0)
-#define GEMM_LSTORE(buf)                                                           \
-    do {                                                                           \
-        unsigned char* _pa = smem + (2 * (buf)) * GBM * LDS_ROW;                   \
-        unsigned char* _pw = smem + (2 * (buf) + 1) * GBM * LDS_ROW;               \
-        *reinterpret_cast<uint4*>(_pa + st_a[0]) = ra0;                            \
-        *reinterpret_cast<uint4*>(_pa + st_a[1]) = ra1;                            \
-        *reinterpret_cast<uint4*>(_pa + st_a[2]) = ra2;                            \
-        *reinterpret_cast<uint4*>(_pa + st_a[3]) = ra3;                            \
-        *reinterpret_cast<uint4*>(_pw + st_w[0]) = rb0;                            \
-        *reinterpret_cast<uint4*>(_pw + st_w[1]) = rb1;                            \
-        *reinterpret_cast<uint4*>(_pw + st_w[2]) = rb2;                            \
-        *reinterpret_cast<uint4*>(_pw + st_w[3]) = rb3;                            \
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        const int r = (wave + NW * i) * 8 + (lane >> 3), pch = lane & 7;
+        w_src[i] = W + (int64_t)(col0 + r) * ldw + ((pch ^ key_w(r)) << 3);
+    }
+#define GEMM_GLDS(buf, kt)                                                                                              \
+    do {                                                                                                                \
+        const int64_t _ko = (int64_t)(kt) * GBK;                                                                        \
+        _Pragma("unroll") for (int _i = 0; _i < GA; ++_i)                                                               \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[_i] + _ko),         \
+                                             (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE + (wave + NW * _i) * 1024), 16, 0, 0); \
+        _Pragma("unroll") for (int _i = 0; _i < GW; ++_i)                                                               \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[_i] + _ko),         \
+                                             (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE + A_BYTES + (wave + NW * _i) * 1024), 16, 0, 0); \
     } while (0)
 
-    f32x4 acc[4][4];      // [m-tile i][n-tile j]
+    f32x4 acc[MI][4];      // [m-tile i][n-tile j]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / GBK;
-    GEMM_GLOAD(0);
-    GEMM_LSTORE(0);
+    GEMM_GLDS(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    // fragment rows of this lane
-    int arow[4], wrow[4];
+    int arow[MI], wrow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        arow[i] = wm * 64 + i * 16 + fr;                             // activation row (B operand column)
-        wrow[i] = wn * 64 + 16 * (fr >> 2) + 4 * i + (fr & 3);       // weight row of MFMA row fr in n-tile i
-    }
+    for (int i = 0; i < MI; ++i) arow[i] = wm * (MI * 16) + i * 16 + fr;              // activation row (B operand column)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wrow[j] = wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);  // weight row of MFMA row fr in n-tile j
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) GEMM_GLOAD(kt + 1);
-        const unsigned char* pa = smem + (2 * buf) * GBM * LDS_ROW;
-        const unsigned char* pw = smem + (2 * buf + 1) * GBM * LDS_ROW;
+        if (kt + 1 < nk) GEMM_GLDS(buf ^ 1, kt + 1);
+        const unsigned char* pa = smem + buf * STAGE;
+        const unsigned char* pw = pa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int ch = 4 * ks + fg;
-            bf16x8 af[4], wf[4];
+            bf16x8 af[MI], wf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ key_act(arow[i])) << 4));
-                wf[i] = *reinterpret_cast<const bf16x8*>(pw + wrow[i] * LDS_ROW + ((ch ^ key_w(wrow[i])) << 4));
-            }
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + wrow[j] * LDS_ROW + ((ch ^ key_w(wrow[j])) << 4));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ key_act(arow[i])) << 4));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) GEMM_LSTORE(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed in LDS
         __syncthreads();
     }
+#undef GEMM_GLDS
 
     // epilogue.  D layout: col = lane & 15 -> output row m; MFMA row 4*fg + r of n-tile j -> output column 16*fg + 4*j + r
     const int n0 = col0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
@@ -179,8 +166,8 @@ __global__ __launch_bounds__(256) void ibl_gemm_bf16_tn(const u16* __restrict__ 
         scale[4 * q] = s4.x; scale[4 * q + 1] = s4.y; scale[4 * q + 2] = s4.z; scale[4 * q + 3] = s4.w;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + wm * 64 + i * 16 + fr;
+    for (int i = 0; i < MI; ++i) {
+        const int row = row0 + wm * (MI * 16) + i * 16 + fr;
         if (row >= M) continue;
         float v[16];
 #pragma unroll
@@ -225,26 +212,33 @@ __global__ __launch_bounds__(256) void ibl_gemm_bf16_tn(const u16* __restrict__ 
     }
 }
 
-template <int EPI>
-static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi,
-                       hipStream_t s) {
-    if (M <= 0) return IBL_OK;
-    if (N % GBN != 0 || K % GBK != 0)
-        return ibl_set_error(IBL_ERR_ARG, "gemm: N (%d) must be a multiple of 128 and K (%d) of 64", N, K);
-    const int nwg = (N / GBN) * ((M + GBM - 1) / GBM);
-    const size_t lds = 4 * GBM * LDS_ROW;
+template <int EPI, int MI, int WM, int WN>
+static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi, hipStream_t s) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64;
+    const int nwg = (N / BN) * ((M + BM - 1) / BM);
+    const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW;
     static bool attr_set = false;
     if (!attr_set) {
-        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI>),
+        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI, MI, WM, WN>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     void* tok;
     ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);
-    hipLaunchKernelGGL(ibl_gemm_bf16_tn<EPI>, dim3(nwg), dim3(256), lds, s, A, lda, W, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((ibl_gemm_bf16_tn<EPI, MI, WM, WN>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
+}
+
+template <int EPI>
+static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi,
+                       hipStream_t s) {
+    if (M <= 0) return IBL_OK;
+    if (N % 128 != 0 || K % GBK != 0)
+        return ibl_set_error(IBL_ERR_ARG, "gemm: N (%d) must be a multiple of 128 and K (%d) of 64", N, K);
+    if (N % 256 == 0 && M >= 4096) return launch_gemm_cfg<EPI, 8, 2, 4>(A, lda, W, ldw, M, N, K, epi, s);
+    return launch_gemm_cfg<EPI, 4, 2, 2>(A, lda, W, ldw, M, N, K, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------------
