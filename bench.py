@@ -212,7 +212,13 @@ def main():
     value = total_frames / dt
 
     if rank == 0:
-        roof = prof.roofline()
+        # HBM traffic per GEMM launch: PMC counters cannot be read in-process, so the figure comes from the committed
+        # rocprofv3 --pmc passes of this same default command (profiles/r01/gemm_pmc.json); null for other workloads
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", "gemm_pmc.json")
+        if os.path.exists(pmc) and (args.model, args.frames, args.q, args.memory) == ("dinov2_vitb14", 32, 7, 1000):
+            traffic = json.load(open(pmc)).get("gemm_traffic_bytes_per_launch")
+        roof = prof.roofline(traffic)
         cpu = None
         if args.cpu_frames > 0:
             v, cdt, threads = cpu_baseline(args, world, mem_emb, batches[args.warmup], args.cpu_frames)

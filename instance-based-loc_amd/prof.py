@@ -21,12 +21,13 @@ def read(kid):
     return ms.value, units.value, n.value
 
 
-def roofline():
-    """Roofline object of the dominant kernel family (the bf16 GEMM of the ViT encoder)."""
+def roofline(traffic=None):
+    """Roofline object of the dominant kernel family (the bf16 GEMM of the ViT encoder).  `traffic` = HBM bytes per
+    launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command (tools/pmc_summary.py)."""
     ms, flops, n = read(GEMM)
     if n == 0 or ms <= 0:
         return None
     achieved = flops / (ms * 1e-3) / 1e12
     return {"kernel": "ibl_gemm_bf16_tn", "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "launches": n, "avg_launch_us": ms * 1e3 / n,
+            "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "launches": n, "avg_launch_us": ms * 1e3 / n,
             "flops_per_launch": flops / n}
