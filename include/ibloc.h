@@ -121,6 +121,16 @@ int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* desc, int batch);
 int ibl_vit_forward(const ibl_vit_desc* desc, const ibl_vit_weights* weights, const void* patches, int batch,
                     float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* One linear layer of the encoder on its own: out = epilogue(x W^T + bias).  The nn.Linear of the reference's
+ * encoders (transformers' ViTSelfAttention / ViTIntermediate / ViTOutput called from utils/embeddings.py:46,69,93).
+ *   x [dev] bf16 [rows][ldx], W [dev] bf16 [n_out][ldw] (nn.Linear layout), bias [dev] fp32 [n_out] or NULL
+ *   epilogue: IBL_LINEAR_BF16 -> out bf16; IBL_LINEAR_GELU_BF16 -> out = gelu(.) bf16 (erf form);
+ *             IBL_LINEAR_RESID_F32 -> out fp32 += scale[n] * (.) (scale NULL = 1); IBL_LINEAR_F32 -> out fp32
+ *   n_out % 128 == 0, n_in % 64 == 0, ldx / ldw / ldo in elements with 16-byte aligned rows */
+enum { IBL_LINEAR_BF16 = 0, IBL_LINEAR_GELU_BF16 = 1, IBL_LINEAR_RESID_F32 = 2, IBL_LINEAR_F32 = 4 };
+int ibl_linear_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, const float* scale,
+                    int64_t rows, int n_out, int n_in, int epilogue, void* out, int64_t ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* DATOR RGB-D encoder                                                       */
 /* ------------------------------------------------------------------------------------------ */

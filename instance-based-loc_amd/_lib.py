@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (device memory and streams are torch's; see DESIGN.md "boundary")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libibloc_hip.so")
+# IBLOC_LIB selects another build of the same library (instrumented lab builds of tools/); never a different backend
+LIB_PATH = os.environ.get("IBLOC_LIB") or os.path.join(_HERE, "libibloc_hip.so")
 
 
 class IblError(RuntimeError):
@@ -44,6 +45,7 @@ _SIGS = {
     "ibl_preprocess_crops": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        vp, vp, vp, vp, vp]),
     "ibl_vit_workspace_bytes": (C.c_int64, [vp, C.c_int]),
+    "ibl_linear_bf16": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),
     "ibl_vit_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),
     "ibl_reg_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int64]),
     "ibl_reg_ctx_destroy": (C.c_int, [vp]),

@@ -66,6 +66,36 @@ __device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r
 // output row: the epilogue is 16-byte vector stores.  Operand tiles are staged with direct-to-LDS loads
 // (global_load_lds_dwordx4): one wave instruction writes 1 KiB = 8 tile rows linearly, so the XOR swizzle is applied
 // to the per-lane SOURCE address.
+// Exact-form GELU, 0.5 v (1 + erf(v / sqrt 2)), with erfc from Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7 in erf, two orders
+// below the bf16 rounding of the stored activation).  libm's erff costs ~35 VALU instructions per element, which made the
+// fc1 epilogue as long as its K loop; this form is 14.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float z = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float c = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erfc(z)
+    return 0.5f * v * (v < 0.f ? c : 2.0f - c);
+}
+
+#ifdef IBL_GEMM_STAMPS     // lab builds only (tools/perf_gemm.py --stamps): per-block phase clocks
+__device__ long long ibl_gemm_stamps[5 * 8192];
+#define GEMM_STAMP(k)                                                                                  \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                   \
+            ibl_gemm_stamps[5 * blockIdx.x + (k)] = (long long)__builtin_amdgcn_s_memtime();           \
+            if ((k) == 0) ibl_gemm_stamps[5 * blockIdx.x + 4] = (long long)__smid();                   \
+        }                                                                                              \
+    } while (0)
+extern "C" int ibl_gemm_stamps_read(long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ibl_gemm_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -1;
+}
+#else
+#define GEMM_STAMP(k)
+#endif
+
 template <int EPI, int MI, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
                                                                   int64_t ldw, int M, int N, int K, GemmEpi epi) {
@@ -121,18 +151,26 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / GBK;
+    GEMM_STAMP(0);
     GEMM_GLDS(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    GEMM_STAMP(1);
     const int fr = lane & 15, fg = lane >> 4;
     int arow[MI], wrow[4];
 #pragma unroll
     for (int i = 0; i < MI; ++i) arow[i] = wm * (MI * 16) + i * 16 + fr;              // activation row (B operand column)
 #pragma unroll
     for (int j = 0; j < 4; ++j) wrow[j] = wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);  // weight row of MFMA row fr in n-tile j
+    // One K step = 2 * MI groups of 4 MFMAs.  The GA + GW direct-to-LDS pieces of the NEXT tile are issued one at a time
+    // between those groups: a piece blocks its wave's issue port for ~100 cycles, and eight of them back to back at the top
+    // of the step (right after the barrier, in every wave at once) left the MFMA pipe idle for a third of the step.
+    constexpr int NG = 2 * MI, NP = GA + GW;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) GEMM_GLDS(buf ^ 1, kt + 1);
+        const bool more = kt + 1 < nk;
+        const int64_t ko = (int64_t)(kt + 1) * GBK;
+        unsigned char* nxt = smem + (buf ^ 1) * STAGE;
         const unsigned char* pa = smem + buf * STAGE;
         const unsigned char* pw = pa + A_BYTES;
 #pragma unroll
@@ -144,15 +182,29 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ key_act(arow[i])) << 4));
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                const int g = ks * MI + i;
+#pragma unroll
+                for (int pc = g * NP / NG; pc < (g + 1) * NP / NG; ++pc) {
+                    if (more) {
+                        if (pc < GA)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[pc] + ko),
+                                                             (__attribute__((address_space(3))) void*)(nxt + (wave + NW * pc) * 1024), 16, 0, 0);
+                        else
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[pc - GA] + ko),
+                                                             (__attribute__((address_space(3))) void*)(nxt + A_BYTES + (wave + NW * (pc - GA)) * 1024), 16, 0, 0);
+                    }
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed in LDS
         __syncthreads();
     }
 #undef GEMM_GLDS
+    GEMM_STAMP(2);
 
     // epilogue.  D layout: col = lane & 15 -> output row m; MFMA row 4*fg + r of n-tile j -> output column 16*fg + 4*j + r
     const int n0 = col0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
@@ -177,7 +229,7 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
         if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
             if (EPI == EPI_BIAS_GELU_BF16) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) v[t] = 0.5f * v[t] * (1.0f + erff(v[t] * 0.70710678118654752f));
+                for (int t = 0; t < 16; ++t) v[t] = gelu_erf(v[t]);
             }
             unsigned int pk[8];
 #pragma unroll
@@ -210,6 +262,11 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
             for (int q = 0; q < 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
     }
+#ifdef IBL_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GEMM_STAMP(3);
+#endif
 }
 
 template <int EPI, int MI, int WM, int WN>
@@ -237,7 +294,9 @@ static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int
     if (M <= 0) return IBL_OK;
     if (N % 128 != 0 || K % GBK != 0)
         return ibl_set_error(IBL_ERR_ARG, "gemm: N (%d) must be a multiple of 128 and K (%d) of 64", N, K);
+#ifndef IBL_GEMM_FORCE128
     if (N % 256 == 0 && M >= 4096) return launch_gemm_cfg<EPI, 8, 2, 4>(A, lda, W, ldw, M, N, K, epi, s);
+#endif
     return launch_gemm_cfg<EPI, 4, 2, 2>(A, lda, W, ldw, M, N, K, epi, s);
 }
 
@@ -451,6 +510,30 @@ __global__ __launch_bounds__(256) void ibl_attention_kernel(const u16* __restric
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 static inline int64_t rows_pad(int64_t r) { return ibl_align_up(r, 128); }
+
+extern "C" int ibl_linear_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, const float* scale,
+                               int64_t rows, int n_out, int n_in, int epilogue, void* out, int64_t ldo, void* stream) {
+    if (rows == 0) return IBL_OK;
+    if (!x || !W || !out) return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: null operand");
+    if (rows < 0 || rows > 0x7fffffff) return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: rows out of range");
+    if ((ldx & 7) || (ldw & 7) || ldx < n_in || ldw < n_in || ldo < n_out || (ldo & 7))
+        return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: row strides must be >= the row length and multiples of 8 elements");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GemmEpi e{};
+    e.bias = bias;
+    e.scale = scale;
+    e.out = out;
+    e.ldo = ldo;
+    const u16* a = reinterpret_cast<const u16*>(x);
+    const u16* w = reinterpret_cast<const u16*>(W);
+    switch (epilogue) {
+        case EPI_BIAS_BF16: return launch_gemm<EPI_BIAS_BF16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
+        case EPI_BIAS_GELU_BF16: return launch_gemm<EPI_BIAS_GELU_BF16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
+        case EPI_RESID_F32: return launch_gemm<EPI_RESID_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
+        case EPI_BIAS_F32: return launch_gemm<EPI_BIAS_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
+        default: return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: unknown epilogue %d", epilogue);
+    }
+}
 
 extern "C" int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* d, int batch) {
     if (!d || batch <= 0) return -1;

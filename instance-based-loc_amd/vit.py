@@ -300,3 +300,31 @@ class VitEncoder:
         for i in range(0, n, max_batch):
             outs.append(self.forward_patches(self.preprocess(crops[i:i + max_batch])))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+
+LINEAR_BF16, LINEAR_GELU_BF16, LINEAR_RESID_F32, LINEAR_F32 = 0, 1, 2, 4
+
+
+def linear_bf16(x: torch.Tensor, W: torch.Tensor, bias=None, epilogue=LINEAR_BF16, out=None, scale=None) -> torch.Tensor:
+    """out = epilogue(x W^T + bias) through `ibl_linear_bf16` (the encoder's GEMM kernel on its own).
+    x (rows, n_in) bf16, W (n_out, n_in) bf16 (nn.Linear layout), bias / scale fp32 (n_out).  LINEAR_RESID_F32
+    accumulates into `out` (fp32), the other epilogues allocate it when it is not given."""
+    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.is_cuda and W.is_cuda
+    assert x.stride(-1) == 1 and W.stride(-1) == 1
+    rows, n_in = x.shape
+    n_out = W.shape[0]
+    if out is None:
+        if epilogue == LINEAR_RESID_F32:
+            raise ValueError("LINEAR_RESID_F32 accumulates into `out`")
+        out = torch.empty((rows, n_out), device=x.device, dtype=torch.float32 if epilogue == LINEAR_F32 else torch.bfloat16)
+    want = torch.float32 if epilogue in (LINEAR_RESID_F32, LINEAR_F32) else torch.bfloat16
+    assert out.dtype == want and out.shape == (rows, n_out) and out.stride(-1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == n_out and bias.is_contiguous()
+    if scale is not None:
+        assert scale.dtype == torch.float32 and scale.numel() == n_out and scale.is_contiguous()
+    st = _lib.lib.ibl_linear_bf16(x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr() if bias is not None else None,
+                                  scale.data_ptr() if scale is not None else None, rows, n_out, n_in, epilogue, out.data_ptr(),
+                                  out.stride(0), torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "ibl_linear_bf16")
+    return out
