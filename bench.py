@@ -246,6 +246,9 @@ def main():
             "cpu_baseline": cpu,
             "stage_ms_per_step": {k: v / args.steps for k, v in timings.items() if isinstance(v, float)},
             "localised_within_0.6m": ok / max(1, args.frames * args.steps),
+            # last step: points whose normals/FPFH/gradients came from the resident instance features, points recomputed in the
+            # context of their job (instances within the influence radius of each other), recomputed groups, job sides
+            "feature_reuse_last_step": timings.get("reuse"),
         }
         print(json.dumps(out))
     if world_size > 1:

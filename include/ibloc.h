@@ -250,6 +250,8 @@ int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* s
  *   IBL_REG_CENTER      subtract each side's mean first (localise does; the stand-alone function does not)
  *   IBL_REG_HAVE_COLORS normals + FPFH + RANSAC + coloured ICP; without it the reference's exception path:
  *                       point-to-point ICP from the identity (fpfh_register.py:137-141)
+ * Normals, FPFH and the targets' colour gradients are evaluated on the concatenations BEFORE centring (they are
+ * translation invariant; see ibl_instance_features); RANSAC and ICP run between the centred clouds.
  * RANSAC hypothesis i of job j is drawn from Philox4x32-10(counter = (i, job_id_base + j, 0, 0), key = seed).
  * Outputs are HOST arrays (the call synchronises): T_out [n_jobs][16] row-major double (between the centred
  * clouds), rmse_out / fitness_out [n_jobs] (result_icp.inlier_rmse / .fitness), means_out [n_jobs][2][3]
@@ -263,6 +265,43 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
                        double global_dist_factor, double local_dist_factor, uint64_t seed, uint32_t job_id_base,
                        int64_t ransac_max_iter, int flags, double* T_out, double* rmse_out, double* fitness_out,
                        double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, void* stream);
+
+/* Per-instance registration features, computed ONCE per cloud and kept resident in HBM instead of once per
+ * (frame, assignment) job: the reference re-runs estimate_normals / compute_fpfh_feature
+ * (utils/fpfh_register.py:86-98) and the colour gradients inside registration_colored_icp
+ * (utils/fpfh_register.py:125-133) on the concatenated clouds of every assignment (object_memory.py:1023-1034,
+ * 1087-1089), although a memory instance never changes and a detected instance is shared by all assignments of its
+ * frame.  Normals, FPFH and colour gradients only depend on point differences, so they are evaluated in the frame
+ * the clouds are stored in (before the per-job centring) and the value at a point of instance A inside a
+ * concatenation A+B+C equals its stand-alone value unless a point of B or C lies within the influence radius
+ *     R = max(2 * 5 * voxel + 2 * voxel, grad_radius + 2 * voxel)
+ * of A.  ibl_register_batch_cached uses the stored values for every instance whose bounding box is at least R
+ * (plus a rounding margin) away from the other instances of its job side and recomputes the rest in the context of
+ * the job's concatenation, which makes its results bit-identical to ibl_register_batch.
+ *   normals4 [dev] N x float4, fpfh [dev] N x 33, grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
+ *   gradients are recomputed per job), bbox [HOST] n_seg x 6 = (min xyz, max xyz) -- all written by
+ *   ibl_instance_features_batch (the call synchronises); voxel_size / grad_radius: the parameters they hold for
+ *   (grad_radius = 2 * voxel_size * local_dist_factor in register_point_clouds). */
+typedef struct {
+    const float* normals4;
+    const float* fpfh;
+    const float* grad4;
+    const float* bbox;
+    double voxel_size;
+    double grad_radius;
+} ibl_instance_features;
+int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
+                                int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh, float* grad4,
+                                float* bbox_host, void* stream);
+/* ibl_register_batch with the instance features of the detected pool and / or the memory pool (either may be NULL) */
+int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                              int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                              int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs, double voxel_size,
+                              double global_dist_factor, double local_dist_factor, uint64_t seed, uint32_t job_id_base,
+                              int64_t ransac_max_iter, int flags, const ibl_instance_features* det_features,
+                              const ibl_instance_features* mem_features, double* T_out, double* rmse_out, double* fitness_out,
+                              double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, int64_t* reuse_stats_out,
+                              void* stream);
 
 /* Persistent spatial hash over ALL memory points (world frame), built once per memory upload from the
  * context arena.  Replaces the KD-tree Open3D rebuilds over `all_memory_pcd` on every evaluate_registration

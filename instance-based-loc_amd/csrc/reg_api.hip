@@ -16,6 +16,9 @@ int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals
 int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,
                             unsigned char* keep, hipStream_t s);
 
+int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
+                          int max_nn, float4* grad, int* status, hipStream_t s);
+
 extern "C" int ibl_reg_ctx_create(ibl_reg_ctx** out, int64_t arena_bytes) {
     if (!out || arena_bytes < (1 << 20)) return ibl_set_error(IBL_ERR_ARG, "ibl_reg_ctx_create: bad argument");
     ibl_reg_ctx* c = new ibl_reg_ctx();
@@ -113,5 +116,95 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
                              nbr_idx, nbr_d2, nbr_cnt, fpfh, ctx->d_status, s);
         if (st) return st;
     }
+    return IBL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// registration features of a batch of clouds (shared by the instance cache and by ibl_register_batch_cached)
+// ------------------------------------------------------------------------------------------------
+int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, double voxel_size,
+                          double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, float4* grad, hipStream_t s) {
+    const int n = seg_off_host[n_seg];
+    if (n <= 0) return IBL_OK;
+    int st;
+    {
+        ArenaMark mA(ctx);
+        BatchGrid gA;
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 2), (int64_t)128 << 20, &gA, s);
+        if (st) return st;
+        st = ibl_launch_normals(gA, P, seg_off_dev, n, voxel_size * 2, 30, normals, ctx->d_status, s);
+        if (st) return st;
+    }
+    if (fpfh) {
+        ArenaMark mB(ctx);
+        BatchGrid gB;
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 5), (int64_t)64 << 20, &gB, s);
+        if (st) return st;
+        unsigned char* spfh; float* nbr_d2; int *nbr_idx, *nbr_cnt;
+        IBL_ARENA(spfh, unsigned char, (int64_t)n * 36 + 64);
+        IBL_ARENA(nbr_idx, int, (int64_t)n * 100 + 64);
+        IBL_ARENA(nbr_d2, float, (int64_t)n * 100 + 64);
+        IBL_ARENA(nbr_cnt, int, n + 64);
+        st = ibl_launch_fpfh(gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, ctx->d_status, s);
+        if (st) return st;
+    }
+    if (grad && gq1 > gq0) {
+        if (grad_radius <= 0) return ibl_set_error(IBL_ERR_ARG, "colour gradients need a positive radius");
+        ArenaMark mG(ctx);
+        BatchGrid gG;      // cell = half the radius (the ICP correspondence distance), reach 2
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(grad_radius * 0.5), (int64_t)128 << 20, &gG, s);
+        if (st) return st;
+        st = ibl_launch_color_grad(gG, P, normals, seg_off_dev, gq0, gq1, grad_radius, 30, grad, ctx->d_status, s);
+        if (st) return st;
+    }
+    return IBL_OK;
+}
+
+extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
+                                           int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh, float* grad4,
+                                           float* bbox_host, void* stream) {
+    if (!ctx || !pts4 || !seg_off_dev || !normals4 || !fpfh || voxel_size <= 0)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_instance_features_batch: bad argument");
+    if (grad4 && grad_radius <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_instance_features_batch: colour gradients need grad_radius > 0");
+    int st = check_seg(seg_off_host, n_seg, "ibl_instance_features_batch");
+    if (st) return st;
+    ArenaMark mark(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    const float4* P = reinterpret_cast<const float4*>(pts4);
+    if (bbox_host && n_seg > 0) {
+        float* bbox;
+        IBL_ARENA(bbox, float, (int64_t)n_seg * 6 + 6);
+        st = ibl_launch_bbox(P, seg_off_dev, n_seg, bbox, s);
+        if (st) return st;
+        IBL_HIP_CHECK(hipMemcpyAsync(bbox_host, bbox, sizeof(float) * 6 * (size_t)n_seg, hipMemcpyDeviceToHost, s));
+    }
+    // chunks of whole clouds bound the scratch (800 B / point of neighbour lists): a 10k-instance memory is 50M points
+    const int64_t chunk_pts = 1 << 20;
+    std::vector<int> rebased;
+    for (int s0 = 0; s0 < n_seg;) {
+        int s1 = s0 + 1;
+        while (s1 < n_seg && (int64_t)seg_off_host[s1 + 1] - seg_off_host[s0] <= chunk_pts) ++s1;
+        const int o0 = seg_off_host[s0], ns = s1 - s0;
+        ArenaMark mc(ctx);
+        const int* off_dev = seg_off_dev;
+        const int* off_host = seg_off_host;
+        if (!(s0 == 0 && s1 == n_seg)) {
+            rebased.resize(ns + 1);
+            for (int i = 0; i <= ns; ++i) rebased[i] = seg_off_host[s0 + i] - o0;
+            int* d;
+            IBL_ARENA(d, int, ns + 1);
+            IBL_HIP_CHECK(hipMemcpyAsync(d, rebased.data(), sizeof(int) * (ns + 1), hipMemcpyHostToDevice, s));
+            IBL_HIP_CHECK(hipStreamSynchronize(s));     // `rebased` is rewritten by the next chunk
+            off_dev = d;
+            off_host = rebased.data();
+        }
+        const int cnt = off_host[ns];
+        st = ibl_features_on_batch(ctx, P + o0, off_dev, off_host, ns, voxel_size, grad_radius, 0, grad4 ? cnt : 0,
+                                   reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33,
+                                   grad4 ? reinterpret_cast<float4*>(grad4) + o0 : nullptr, s);
+        if (st) return st;
+        s0 = s1;
+    }
+    IBL_HIP_CHECK(hipStreamSynchronize(s));
     return IBL_OK;
 }

@@ -78,6 +78,9 @@ static inline T* arena_alloc(ibl_reg_ctx* ctx, int64_t count, bool* ok) {
 int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
                          float cell, int64_t max_cells, BatchGrid* out, hipStream_t s);
 
+// per-segment axis-aligned bounding boxes [S][6] = (min xyz, max xyz); empty segments read as zeros
+int ibl_launch_bbox(const float4* pts, const int* seg_off_dev, int n_seg, float* bbox_dev, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------

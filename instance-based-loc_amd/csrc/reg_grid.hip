@@ -37,6 +37,13 @@ __global__ __launch_bounds__(256) void ibl_bbox_kernel(const float4* __restrict_
     }
 }
 
+int ibl_launch_bbox(const float4* pts, const int* seg_off_dev, int n_seg, float* bbox_dev, hipStream_t s) {
+    if (n_seg <= 0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox_dev);
+    IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
+
 // single block: per-segment grid dimensions and the cell-base prefix (S is small)
 __global__ void ibl_grid_dims_kernel(const float* __restrict__ bbox, int n_seg, float cell, long long max_cells,
                                      SegGrid* __restrict__ seg, int* __restrict__ total_cells, int* __restrict__ status) {

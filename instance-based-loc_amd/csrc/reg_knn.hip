@@ -331,21 +331,53 @@ __device__ inline void fast_eigen_normal_d(const double* cov, double* n) {
 // ------------------------------------------------------------------------------------------------
 // consumers
 // ------------------------------------------------------------------------------------------------
+// The selected neighbours arrive in the enumeration order of the grid.  Consumers reduce them in ascending ORIGINAL
+// point index instead (rank sort of the <= 256 list entries in LDS), so that every floating-point sum is independent
+// of the grid a cloud was enumerated from: features of an instance computed on its own (ibl_instance_features_batch)
+// are bit-identical to those computed inside a concatenation whose other instances are out of reach.
+// in: L->sel_j[0..k) (+ sel_d2); out: L->b_j[0..k) (+ b_bits = d2 bits) in ascending order[j].
+template <bool WITH_D2>
+__device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const int* __restrict__ order, int k) {
+    const int lane = threadIdx.x & 63;
+    wave_lds_sync();
+    for (int t = lane; t < k; t += 64) L->b_idx[t] = order[L->sel_j[t]];
+    wave_lds_sync();
+    for (int t = lane; t < k; t += 64) {
+        const int key = L->b_idx[t];
+        int r = 0;
+        for (int u = 0; u < k; ++u) r += L->b_idx[u] < key ? 1 : 0;
+        L->b_j[r] = L->sel_j[t];
+        if (WITH_D2) L->b_bits[r] = __float_as_uint(L->sel_d2[t]);
+    }
+    wave_lds_sync();
+}
 struct NormalConsumer {
     float4* normals;
+    const int* order;
+    const float4* sorted;
+    WaveLds* L;
     int qi;
-    double c[9];
-    __device__ void begin(int) { for (int t = 0; t < 9; ++t) c[t] = 0.0; }
-    __device__ void accept(bool sel, int, const float4& p, float) {
-        if (sel) {
+    int ncount;
+    __device__ void begin(int) { ncount = 0; }
+    __device__ void accept(bool sel, int j, const float4&, float) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long m = __ballot(sel);
+        if (sel) L->sel_j[ncount + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        ncount += __popcll(m);
+    }
+    __device__ void finish(int k) {
+        const int lane = threadIdx.x & 63;
+        sort_selected_by_index<false>(L, order, k);
+        double c[9];
+        for (int t = 0; t < 9; ++t) c[t] = 0.0;
+        for (int t = lane; t < k; t += 64) {
+            const float4 p = sorted[L->b_j[t]];
             const double x = p.x, y = p.y, z = p.z;
             c[0] += x; c[1] += y; c[2] += z;
             c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
         }
-    }
-    __device__ void finish(int k) {
         for (int t = 0; t < 9; ++t) c[t] = wave_sum_d(c[t]);
-        if ((threadIdx.x & 63) == 0) {
+        if (lane == 0) {
             double n[3];
             if (k >= 3) {
                 for (int t = 0; t < 9; ++t) c[t] /= (double)k;
@@ -424,12 +456,12 @@ struct SpfhConsumer {
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
         int* hist = L->scratch;
-        wave_lds_sync();
+        sort_selected_by_index<true>(L, order, k);
         for (int t = lane; t < k; t += 64) {
-            const int j = L->sel_j[t];
+            const int j = L->b_j[t];
             const int jo = order[j];
             nbr_idx[(int64_t)qi * K + t] = jo;
-            nbr_d2[(int64_t)qi * K + t] = L->sel_d2[t];
+            nbr_d2[(int64_t)qi * K + t] = __uint_as_float(L->b_bits[t]);
             if (jo != qi) {
                 double f[3];
                 pair_features_d(q, qn, sorted[j], normals[jo], f);
@@ -464,11 +496,11 @@ struct GradConsumer {
     }
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
-        wave_lds_sync();
+        sort_selected_by_index<false>(L, order, k);
         double a[9];             // AtA (6 unique: 00 01 02 11 12 22) + Atb (3)
         for (int t = 0; t < 9; ++t) a[t] = 0.0;
         for (int t = lane; t < k; t += 64) {
-            const int j = L->sel_j[t];
+            const int j = L->b_j[t];
             if (order[j] == qi) continue;
             const float4 p = sorted[j];
             const double vt[3] = {q.x, q.y, q.z}, nt[3] = {qn.x, qn.y, qn.z};
@@ -515,7 +547,7 @@ __global__ __launch_bounds__(256) void ibl_normals_kernel(BatchGrid g, const flo
     if (qi >= n) return;
     const int s = seg_of(seg_off, g.n_seg, qi);
     NormalConsumer cons;
-    cons.normals = normals; cons.qi = qi;
+    cons.normals = normals; cons.qi = qi; cons.order = g.order; cons.sorted = g.sorted_pts; cons.L = &lds[threadIdx.x >> 6];
     hybrid_select(g, g.seg[s], pts[qi], qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
 }
 
@@ -644,6 +676,7 @@ __global__ __launch_bounds__(256) void ibl_radius_count_kernel(BatchGrid g, cons
 int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
                        int* status, hipStream_t s) {
     if (n <= 0) return IBL_OK;
+    if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "normals: max_nn %d > 256", max_nn);
     hipLaunchKernelGGL(ibl_normals_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, seg_off, (float)radius,
                        (float)(radius * radius), max_nn, normals, status);
     IBL_LAUNCH_CHECK();

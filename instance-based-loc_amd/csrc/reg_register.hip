@@ -14,18 +14,18 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <map>
 #include <vector>
 
 #include "ibloc.h"
 #include "reg_common.h"
 
-int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
-                       int* status, hipStream_t s);
-int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
-                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
-int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
-                          int max_nn, float4* grad, int* status, hipStream_t s);
+// normals (radius 2 voxel, 30 nn) and FPFH (5 voxel, 100 nn) of every cloud of a batch, colour gradients (grad_radius, 30 nn) of
+// the points [gq0, gq1) -- reg_api.hip
+int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, double voxel_size,
+                          double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, float4* grad, hipStream_t s);
 
 #define ICP_BPJ 32       // blocks per job in the ICP / evaluation reductions
 #define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
@@ -88,6 +88,55 @@ __global__ __launch_bounds__(256) void ibl_job_gather_kernel(const JobDesc* __re
     }
     const double* m = means + (j * 2 + side) * 3;
     out[i] = make_float4((float)((double)p.x - m[0]), (float)((double)p.y - m[1]), (float)((double)p.z - m[2]), p.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature stage: recomputed groups (raw concatenations of the instances that influence each other) and the
+// assembly of the per-job feature arrays from the instance caches / the recomputed groups
+// ------------------------------------------------------------------------------------------------
+struct GroupDesc { int pool; int seg[3]; };          // pool 0 = detected, 1 = memory; -1 = unused slot
+struct FeatCopy { int dst, src, count, kind; };      // kind & 3: 0 detected cache, 1 memory cache, 2 recomputed groups
+#define FEATCOPY_GRAD 4                              // also copy the colour gradients (target sides)
+struct FeatSources { const float4* normals[3]; const float* fpfh[3]; const float4* grad[3]; };
+
+__global__ __launch_bounds__(256) void ibl_group_gather_kernel(const GroupDesc* __restrict__ groups, int G, const float4* __restrict__ det,
+                                                               const int* __restrict__ det_off, const float4* __restrict__ mem,
+                                                               const int* __restrict__ mem_off, const int* __restrict__ grp_off,
+                                                               float4* __restrict__ out) {
+    const int n = grp_off[G];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int g = seg_of(grp_off, G, i);
+    int local = i - grp_off[g];
+    const float4* pool = groups[g].pool ? mem : det;
+    const int* off = groups[g].pool ? mem_off : det_off;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < 3; ++t) {
+        const int sg = groups[g].seg[t];
+        if (sg < 0) continue;
+        const int len = off[sg + 1] - off[sg];
+        if (local < len) { p = pool[off[sg] + local]; break; }
+        local -= len;
+    }
+    out[i] = p;
+}
+
+// grid (tiles, copies): contiguous block copies (an instance's features are contiguous at both ends)
+__global__ __launch_bounds__(256) void ibl_feat_assemble_kernel(const FeatCopy* __restrict__ copies, FeatSources src, float4* __restrict__ normals,
+                                                                float* __restrict__ fpfh, float4* __restrict__ grad) {
+    const FeatCopy c = copies[blockIdx.y];
+    const int k = c.kind & 3;
+    const float* sf = src.fpfh[k] + (int64_t)c.src * 33;
+    float* df = fpfh + (int64_t)c.dst * 33;
+    const int nf = c.count * 33;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf; i += gridDim.x * 256) df[i] = sf[i];
+    const float4* sn = src.normals[k] + c.src;
+    const float4* sg = src.grad[k] + c.src;
+    const bool want_grad = (c.kind & FEATCOPY_GRAD) != 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < c.count; i += gridDim.x * 256) {
+        normals[c.dst + i] = sn[i];
+        if (want_grad) grad[c.dst + i] = sg[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -658,6 +707,20 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
                                   double global_dist_factor, double local_dist_factor, uint64_t seed, uint32_t job_id_base,
                                   int64_t ransac_max_iter, int flags, double* T_out, double* rmse_out, double* fitness_out,
                                   double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, void* stream) {
+    return ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
+                                     job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed, job_id_base,
+                                     ransac_max_iter, flags, nullptr, nullptr, T_out, rmse_out, fitness_out, means_out, T_ransac_out,
+                                     ransac_stats_out, nullptr, stream);
+}
+
+extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                                         int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                                         int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs,
+                                         double voxel_size, double global_dist_factor, double local_dist_factor, uint64_t seed,
+                                         uint32_t job_id_base, int64_t ransac_max_iter, int flags,
+                                         const ibl_instance_features* det_features, const ibl_instance_features* mem_features,
+                                         double* T_out, double* rmse_out, double* fitness_out, double* means_out, double* T_ransac_out,
+                                         int64_t* ransac_stats_out, int64_t* reuse_stats_out, void* stream) {
     if (!ctx || !det_pts4 || !mem_pts4 || !det_off_dev || !mem_off_dev || !det_off_host || !mem_off_host || !job_src_seg || !job_tgt_seg ||
         !T_out || !rmse_out || !fitness_out)
         return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch: null pointer");
@@ -718,34 +781,147 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
     st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)max_dist_icp, (int64_t)128 << 20, &gC, s);
     if (st) return st;
     float4* grad = nullptr;
+    // host-side plans of the feature stage; they must outlive their H2D copies (synchronised in the RANSAC prologue)
+    std::vector<GroupDesc> groups;
+    std::vector<int> grp_off;
+    std::vector<FeatCopy> copies;
     if (colored) {
-        {
-            ArenaMark mA(ctx);
-            BatchGrid gA;
-            st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(voxel_size * 2), (int64_t)128 << 20, &gA, s);
-            if (st) return st;
-            st = ibl_launch_normals(gA, P, d_job_off, N, voxel_size * 2, 30, normals, ctx->d_status, s);
-            if (st) return st;
-        }
+        IBL_ARENA(grad, float4, N + 1);
         IBL_ARENA(rs, RansacState, J);
         int2* corr; int* n_corr;
         IBL_ARENA(corr, int2, Ns + 1);
         IBL_ARENA(n_corr, int, J + 1);
         {
-            // ---- FPFH + matching (scratch released afterwards) ---------------------------------------
+            // ---- normals + FPFH + colour gradients (instance cache / recomputed groups), then matching ----------
             ArenaMark m2(ctx);
-            BatchGrid gB;
-            st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(voxel_size * 5), (int64_t)64 << 20, &gB, s);
-            if (st) return st;
-            unsigned char* spfh; float *fpfh, *nbr_d2; int *nbr_idx, *nbr_cnt, *nn;
-            IBL_ARENA(spfh, unsigned char, (int64_t)N * 36 + 64);
+            float* fpfh; int* nn;
             IBL_ARENA(fpfh, float, (int64_t)N * 33 + 64);
-            IBL_ARENA(nbr_idx, int, (int64_t)N * 100 + 64);
-            IBL_ARENA(nbr_d2, float, (int64_t)N * 100 + 64);
-            IBL_ARENA(nbr_cnt, int, N + 64);
             IBL_ARENA(nn, int, N + 64);
-            st = ibl_launch_fpfh(gB, P, normals, d_job_off, N, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, ctx->d_status, s);
-            if (st) return st;
+            const double grad_radius = max_dist_icp * 2.0;
+            const ibl_instance_features* feat[2] = {det_features, mem_features};
+            for (int pl = 0; pl < 2; ++pl) {
+                if (!feat[pl]) continue;
+                if (!feat[pl]->normals4 || !feat[pl]->fpfh || !feat[pl]->bbox)
+                    return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_cached: instance features with null arrays");
+                if (fabs(feat[pl]->voxel_size - voxel_size) > 1e-12 * voxel_size)
+                    return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_cached: instance features were built for voxel_size %g, not %g",
+                                         feat[pl]->voxel_size, voxel_size);
+                if (pl == 1 && (!feat[pl]->grad4 || fabs(feat[pl]->grad_radius - grad_radius) > 1e-12 * grad_radius))
+                    return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_cached: memory features need colour gradients of radius %g "
+                                         "(2 * voxel_size * local_dist_factor)", grad_radius);
+            }
+            // influence radius of a foreign point on the features of an instance (see ibloc.h) + rounding margin
+            const double rn = voxel_size * 2, rf = voxel_size * 5;
+            const double R = std::max(2 * rf + rn, grad_radius + rn) * 1.001 + 1e-4;
+            // ---- plan: which instances of every job side keep their stand-alone features -------------------------
+            std::map<std::array<int, 4>, int> gid[2];
+            std::vector<std::array<int, 4>> gkeys[2];
+            struct SlotPlan { int dst, count, pool, seg, grp, pos; };
+            std::vector<SlotPlan> slots;
+            slots.reserve((size_t)6 * J);
+            int64_t pts_cached = 0;
+            for (int sgi = 0; sgi < 2 * J; ++sgi) {
+                const int pl = sgi >= J ? 1 : 0, j = pl ? sgi - J : sgi;
+                const int* segs = pl ? jobs[j].tgt_seg : jobs[j].src_seg;
+                const int* off = pl ? mem_off_host : det_off_host;
+                bool dirty[3] = {false, false, false};
+                for (int a = 0; a < 3; ++a) {
+                    if (segs[a] < 0) continue;
+                    if (!feat[pl]) { dirty[a] = true; continue; }
+                    const float* ba = feat[pl]->bbox + 6 * (size_t)segs[a];
+                    for (int b = 0; b < 3; ++b) {
+                        if (b == a || segs[b] < 0) continue;
+                        const float* bb = feat[pl]->bbox + 6 * (size_t)segs[b];
+                        double g2 = 0;
+                        for (int c = 0; c < 3; ++c) {
+                            const double gap = std::max(0.0, std::max((double)ba[c] - (double)bb[3 + c], (double)bb[c] - (double)ba[3 + c]));
+                            g2 += gap * gap;
+                        }
+                        if (g2 < R * R) dirty[a] = true;
+                    }
+                }
+                std::array<int, 4> key = {pl, -1, -1, -1};
+                int nd = 0, pos[3] = {0, 0, 0}, acc = 0;
+                for (int a = 0; a < 3; ++a)
+                    if (segs[a] >= 0 && dirty[a]) { key[1 + nd++] = segs[a]; pos[a] = acc; acc += off[segs[a] + 1] - off[segs[a]]; }
+                int g = -1;
+                if (nd > 0) {
+                    auto it = gid[pl].find(key);
+                    if (it == gid[pl].end()) { g = (int)gkeys[pl].size(); gid[pl][key] = g; gkeys[pl].push_back(key); }
+                    else g = it->second;
+                }
+                int dst = job_off[sgi];
+                for (int a = 0; a < 3; ++a) {
+                    if (segs[a] < 0) continue;
+                    const int cnt = off[segs[a] + 1] - off[segs[a]];
+                    slots.push_back({dst, cnt, pl, segs[a], dirty[a] ? g : -1, pos[a]});
+                    if (!dirty[a]) pts_cached += cnt;
+                    dst += cnt;
+                }
+            }
+            // recomputed groups: detected-pool groups first, memory-pool groups last (their points get colour gradients)
+            const int G0 = (int)gkeys[0].size(), G = G0 + (int)gkeys[1].size();
+            groups.resize(G);
+            grp_off.assign(G + 1, 0);
+            for (int g = 0; g < G; ++g) {
+                const std::array<int, 4>& k = g < G0 ? gkeys[0][g] : gkeys[1][g - G0];
+                const int* off = k[0] ? mem_off_host : det_off_host;
+                groups[g].pool = k[0];
+                int cnt = 0;
+                for (int t = 0; t < 3; ++t) { groups[g].seg[t] = k[1 + t]; if (k[1 + t] >= 0) cnt += off[k[1 + t] + 1] - off[k[1 + t]]; }
+                grp_off[g + 1] = grp_off[g] + cnt;
+            }
+            const int Nd = grp_off[G];
+            if (reuse_stats_out) { reuse_stats_out[0] = pts_cached; reuse_stats_out[1] = Nd; reuse_stats_out[2] = G; reuse_stats_out[3] = 2 * J; }
+            copies.reserve(slots.size());
+            for (const SlotPlan& sp : slots) {
+                if (sp.count <= 0) continue;
+                FeatCopy c;
+                c.dst = sp.dst; c.count = sp.count;
+                if (sp.grp < 0) { c.kind = sp.pool; c.src = (sp.pool ? mem_off_host : det_off_host)[sp.seg]; }
+                else { c.kind = 2; c.src = grp_off[(sp.pool ? G0 : 0) + sp.grp] + sp.pos; }
+                if (sp.pool == 1) c.kind |= FEATCOPY_GRAD;
+                copies.push_back(c);
+            }
+            {
+                ArenaMark md(ctx);
+                FeatSources src{};
+                for (int pl = 0; pl < 2; ++pl)
+                    if (feat[pl]) {
+                        src.normals[pl] = reinterpret_cast<const float4*>(feat[pl]->normals4);
+                        src.fpfh[pl] = feat[pl]->fpfh;
+                        src.grad[pl] = reinterpret_cast<const float4*>(feat[pl]->grad4);
+                    }
+                if (Nd > 0) {
+                    GroupDesc* d_groups; int* d_grp_off; float4 *Pd, *normals_d, *grad_d; float* fpfh_d;
+                    IBL_ARENA(d_groups, GroupDesc, G);
+                    IBL_ARENA(d_grp_off, int, G + 1);
+                    IBL_ARENA(Pd, float4, Nd + 1);
+                    IBL_ARENA(normals_d, float4, Nd + 1);
+                    IBL_ARENA(grad_d, float4, Nd + 1);
+                    IBL_ARENA(fpfh_d, float, (int64_t)Nd * 33 + 64);
+                    IBL_HIP_CHECK(hipMemcpyAsync(d_groups, groups.data(), sizeof(GroupDesc) * G, hipMemcpyHostToDevice, s));
+                    IBL_HIP_CHECK(hipMemcpyAsync(d_grp_off, grp_off.data(), sizeof(int) * (G + 1), hipMemcpyHostToDevice, s));
+                    hipLaunchKernelGGL(ibl_group_gather_kernel, dim3((Nd + 255) / 256), dim3(256), 0, s, d_groups, G, det, det_off_dev, mem,
+                                       mem_off_dev, d_grp_off, Pd);
+                    IBL_LAUNCH_CHECK();
+                    st = ibl_features_on_batch(ctx, Pd, d_grp_off, grp_off.data(), G, voxel_size, grad_radius, grp_off[G0], Nd, normals_d, fpfh_d,
+                                               grad_d, s);
+                    if (st) return st;
+                    src.normals[2] = normals_d; src.fpfh[2] = fpfh_d; src.grad[2] = grad_d;
+                }
+                if (!copies.empty()) {
+                    FeatCopy* d_copies;
+                    IBL_ARENA(d_copies, FeatCopy, (int64_t)copies.size());
+                    IBL_HIP_CHECK(hipMemcpyAsync(d_copies, copies.data(), sizeof(FeatCopy) * copies.size(), hipMemcpyHostToDevice, s));
+                    for (size_t c0 = 0; c0 < copies.size(); c0 += 32768) {
+                        const unsigned nc = (unsigned)std::min<size_t>(32768, copies.size() - c0);
+                        hipLaunchKernelGGL(ibl_feat_assemble_kernel, dim3(24, nc), dim3(256), 0, s, d_copies + c0, src, normals, fpfh, grad);
+                        IBL_LAUNCH_CHECK();
+                    }
+                }
+                IBL_HIP_CHECK(hipStreamSynchronize(s));     // the scratch below the mark is reused by the matching kernels' successors
+            }
             int max_seg = 1;
             for (int i = 0; i < 2 * J; ++i) max_seg = std::max(max_seg, job_off[i + 1] - job_off[i]);
             hipLaunchKernelGGL(ibl_feat_nn_kernel, dim3((max_seg + 255) / 256, 2 * J), dim3(256), 0, s, fpfh, d_job_off, J, nn);
@@ -821,10 +997,6 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
                 if (round_size < max_round) round_size = std::min(max_round, round_size * 8);
             }
         }
-        // ---- colour gradients of the targets --------------------------------------------------------
-        IBL_ARENA(grad, float4, N + 1);
-        st = ibl_launch_color_grad(gC, P, normals, d_job_off, Ns, N, max_dist_icp * 2.0, 30, grad, ctx->d_status, s);
-        if (st) return st;
     }
     // ---- ICP ------------------------------------------------------------------------------------------
     {

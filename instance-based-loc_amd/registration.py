@@ -99,16 +99,52 @@ def normals_fpfh_batch(ctx: RegContext, batch: CloudBatch, radius_normal, max_nn
     return normals[:batch.n], (fpfh[:batch.n] if fpfh is not None else None)
 
 
+class _FeatStruct(C.Structure):
+    _fields_ = [("normals4", C.c_void_p), ("fpfh", C.c_void_p), ("grad4", C.c_void_p), ("bbox", C.c_void_p),
+                ("voxel_size", C.c_double), ("grad_radius", C.c_double)]
+
+
+class InstanceFeatures:
+    """Registration features of every cloud of a batch, resident on the device (ibl_instance_features): normals,
+    FPFH and (for memory instances) colour gradients, plus host bounding boxes."""
+
+    def __init__(self, normals, fpfh, grad, bbox, voxel_size, grad_radius):
+        self.normals, self.fpfh, self.grad, self.bbox = normals, fpfh, grad, bbox
+        self.voxel_size, self.grad_radius = float(voxel_size), float(grad_radius)
+
+    def as_struct(self):
+        return _FeatStruct(self.normals.data_ptr(), self.fpfh.data_ptr(), self.grad.data_ptr() if self.grad is not None else None,
+                           self.bbox.ctypes.data, self.voxel_size, self.grad_radius)
+
+
+def instance_features_batch(ctx: RegContext, batch: CloudBatch, voxel_size: float, grad_radius: float = 0.0) -> InstanceFeatures:
+    """Normals (2 voxel, 30 nn), FPFH (5 voxel, 100 nn) and, with grad_radius > 0, colour gradients (grad_radius, 30 nn) of
+    every cloud on its own, in the frame it is stored in -- what ibl_register_batch_cached reuses across jobs."""
+    dev = batch.pts4.device
+    n = max(batch.n, 1)
+    normals = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    fpfh = torch.empty((n, 33), dtype=torch.float32, device=dev)
+    grad = torch.empty((n, 4), dtype=torch.float32, device=dev) if grad_radius > 0 else None
+    bbox = np.zeros((max(batch.n_seg, 1), 6), dtype=np.float32)
+    st = _lib.lib.ibl_instance_features_batch(ctx.handle, batch.pts4.data_ptr(), batch.seg_off.data_ptr(), batch.seg_off_host.ctypes.data,
+                                              batch.n_seg, float(voxel_size), float(grad_radius), normals.data_ptr(), fpfh.data_ptr(),
+                                              grad.data_ptr() if grad is not None else None, bbox.ctypes.data, _stream())
+    _lib.check(st, "ibl_instance_features_batch")
+    return InstanceFeatures(normals, fpfh, grad, bbox, voxel_size, grad_radius)
+
+
 REG_HAVE_COLORS = 1
 REG_CENTER = 2
 
 
 def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_seg, job_tgt_seg, voxel_size,
                    global_dist_factor=1.5, local_dist_factor=0.4, seed=0, job_id_base=0, ransac_max_iter=4000000,
-                   have_colors=True, center=True):
+                   have_colors=True, center=True, det_features: InstanceFeatures = None, mem_features: InstanceFeatures = None):
     """Batched register_point_clouds (utils/fpfh_register.py:100-143).  job_*_seg: (J, <=3) int arrays of
-    pool segment ids (-1 padded).  Returns dict of host arrays: T (J,4,4), rmse, fitness, means (J,2,3),
-    T_ransac (J,4,4), ransac_stats (J,3)."""
+    pool segment ids (-1 padded).  det_features / mem_features: instance features of the two pools
+    (instance_features_batch); the results do not depend on them, only the work does.  Returns dict of host arrays:
+    T (J,4,4), rmse, fitness, means (J,2,3), T_ransac (J,4,4), ransac_stats (J,3), reuse (points served by the instance
+    features, points recomputed, recomputed groups, job sides)."""
     def pad(a):
         a = np.asarray(a, dtype=np.int32)
         if a.ndim == 1:
@@ -127,14 +163,19 @@ def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_se
     Tr = np.zeros((J, 16), dtype=np.float64)
     stats = np.zeros((J, 3), dtype=np.int64)
     flags = (REG_HAVE_COLORS if have_colors else 0) | (REG_CENTER if center else 0)
-    st = _lib.lib.ibl_register_batch(ctx.handle, det.pts4.data_ptr(), det.seg_off.data_ptr(), det.seg_off_host.ctypes.data,
-                                     det.n_seg, mem.pts4.data_ptr(), mem.seg_off.data_ptr(), mem.seg_off_host.ctypes.data,
-                                     mem.n_seg, js.ctypes.data, jt.ctypes.data, J, float(voxel_size), float(global_dist_factor),
-                                     float(local_dist_factor), int(seed), int(job_id_base), int(ransac_max_iter), flags,
-                                     T.ctypes.data, rmse.ctypes.data, fit.ctypes.data, means.ctypes.data, Tr.ctypes.data,
-                                     stats.ctypes.data, _stream())
-    _lib.check(st, "ibl_register_batch")
-    return dict(T=T.reshape(J, 4, 4), rmse=rmse, fitness=fit, means=means, T_ransac=Tr.reshape(J, 4, 4), ransac_stats=stats)
+    reuse = np.zeros(4, dtype=np.int64)
+    df = det_features.as_struct() if det_features is not None else None
+    mf = mem_features.as_struct() if mem_features is not None else None
+    st = _lib.lib.ibl_register_batch_cached(ctx.handle, det.pts4.data_ptr(), det.seg_off.data_ptr(), det.seg_off_host.ctypes.data,
+                                            det.n_seg, mem.pts4.data_ptr(), mem.seg_off.data_ptr(), mem.seg_off_host.ctypes.data,
+                                            mem.n_seg, js.ctypes.data, jt.ctypes.data, J, float(voxel_size), float(global_dist_factor),
+                                            float(local_dist_factor), int(seed), int(job_id_base), int(ransac_max_iter), flags,
+                                            C.byref(df) if df is not None else None, C.byref(mf) if mf is not None else None,
+                                            T.ctypes.data, rmse.ctypes.data, fit.ctypes.data, means.ctypes.data, Tr.ctypes.data,
+                                            stats.ctypes.data, reuse.ctypes.data, _stream())
+    _lib.check(st, "ibl_register_batch_cached")
+    return dict(T=T.reshape(J, 4, 4), rmse=rmse, fitness=fit, means=means, T_ransac=Tr.reshape(J, 4, 4), ransac_stats=stats,
+                reuse=reuse)
 
 
 class MemGrid:

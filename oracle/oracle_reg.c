@@ -843,10 +843,17 @@ void oracle_icp(const float* src, const float* src_int, int ns, const float* tgt
 /* register_point_clouds (utils/fpfh_register.py:100-143)                                       */
 /* have_colors == 0 models the exception path: point-to-point ICP from identity                 */
 /* ------------------------------------------------------------------------------------------ */
-void oracle_register(const float* src, const float* src_int, int ns, const float* tgt, const float* tgt_int, int nt,
-                     double voxel, double global_factor, double local_factor, int have_colors, uint64_t seed, uint32_t job_id,
-                     int ransac_max_iter, double T_out[16], double* rmse_out, double* fitness_out, double* T_ransac_out,
-                     int64_t* ransac_stats) {
+/* src_raw / tgt_raw (NULL = src / tgt): the same clouds before the caller centred them.  Normals, FPFH and   */
+/* colour gradients are translation invariant; the product evaluates them in the frame the clouds are stored  */
+/* in (so that per-instance results can be kept), and this restatement follows it: features from the raw      */
+/* coordinates, RANSAC and ICP between the centred clouds (the reference computes all of it on the centred    */
+/* clouds in double precision, where the two orders agree to ~1e-16).                                          */
+void oracle_register_raw(const float* src, const float* src_raw, const float* src_int, int ns, const float* tgt, const float* tgt_raw,
+                         const float* tgt_int, int nt, double voxel, double global_factor, double local_factor, int have_colors,
+                         uint64_t seed, uint32_t job_id, int ransac_max_iter, double T_out[16], double* rmse_out, double* fitness_out,
+                         double* T_ransac_out, int64_t* ransac_stats) {
+    if (!src_raw) src_raw = src;
+    if (!tgt_raw) tgt_raw = tgt;
     double I[16];
     for (int i = 0; i < 16; ++i) I[i] = (i % 5) == 0;
     int iters;
@@ -860,10 +867,10 @@ void oracle_register(const float* src, const float* src_int, int ns, const float
     float* nt_n = (float*)malloc(sizeof(float) * 3 * (size_t)nt);
     float* fs = (float*)malloc(sizeof(float) * 33 * (size_t)ns);
     float* ft = (float*)malloc(sizeof(float) * 33 * (size_t)nt);
-    oracle_normals(src, ns, voxel * 2, 30, ns_n);
-    oracle_normals(tgt, nt, voxel * 2, 30, nt_n);
-    oracle_fpfh(src, ns_n, ns, voxel * 5, 100, fs);
-    oracle_fpfh(tgt, nt_n, nt, voxel * 5, 100, ft);
+    oracle_normals(src_raw, ns, voxel * 2, 30, ns_n);
+    oracle_normals(tgt_raw, nt, voxel * 2, 30, nt_n);
+    oracle_fpfh(src_raw, ns_n, ns, voxel * 5, 100, fs);
+    oracle_fpfh(tgt_raw, nt_n, nt, voxel * 5, 100, ft);
     int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)ns);
     int nc = oracle_feature_match(fs, ns, ft, nt, 1, 3, corr);
     double Tr[16];
@@ -871,7 +878,15 @@ void oracle_register(const float* src, const float* src_int, int ns, const float
     if (T_ransac_out) memcpy(T_ransac_out, Tr, sizeof(Tr));
     float* grad = (float*)malloc(sizeof(float) * 3 * (size_t)nt);
     double md = voxel * local_factor;
-    oracle_color_gradient(tgt, nt_n, tgt_int, nt, md * 2.0, 30, grad);
+    oracle_color_gradient(tgt_raw, nt_n, tgt_int, nt, md * 2.0, 30, grad);
     oracle_icp(src, src_int, ns, tgt, nt_n, tgt_int, grad, nt, md, Tr, 1, 0.968, 30, 1e-6, 1e-6, T_out, fitness_out, rmse_out, &iters);
     free(ns_n); free(nt_n); free(fs); free(ft); free(corr); free(grad);
+}
+
+void oracle_register(const float* src, const float* src_int, int ns, const float* tgt, const float* tgt_int, int nt,
+                     double voxel, double global_factor, double local_factor, int have_colors, uint64_t seed, uint32_t job_id,
+                     int ransac_max_iter, double T_out[16], double* rmse_out, double* fitness_out, double* T_ransac_out,
+                     int64_t* ransac_stats) {
+    oracle_register_raw(src, NULL, src_int, ns, tgt, NULL, tgt_int, nt, voxel, global_factor, local_factor, have_colors, seed, job_id,
+                        ransac_max_iter, T_out, rmse_out, fitness_out, T_ransac_out, ransac_stats);
 }

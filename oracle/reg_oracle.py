@@ -89,16 +89,21 @@ def evaluate(src, tgt, T, max_dist=0.02):
 
 
 def register_point_clouds(src, src_int, tgt, tgt_int, voxel_size, global_dist_factor=1.5, local_dist_factor=0.4, seed=0,
-                          job_id=0, ransac_max_iter=4000000, have_colors=True):
-    """== utils/fpfh_register.py:100-143; returns (T 4x4, inlier_rmse, fitness, T_ransac, ransac_stats)."""
+                          job_id=0, ransac_max_iter=4000000, have_colors=True, src_raw=None, tgt_raw=None):
+    """== utils/fpfh_register.py:100-143; returns (T 4x4, inlier_rmse, fitness, T_ransac, ransac_stats).
+    src_raw / tgt_raw: the clouds before the caller centred them (features are evaluated there, see oracle_reg.c)."""
     src, tgt = _f32(src), _f32(tgt)
+    sr = _f32(src_raw) if src_raw is not None else None
+    tr = _f32(tgt_raw) if tgt_raw is not None else None
+    assert sr is None or sr.shape == src.shape
+    assert tr is None or tr.shape == tgt.shape
     T = np.zeros(16, dtype=np.float64)
     Tr = np.zeros(16, dtype=np.float64)
     stats = np.zeros(3, dtype=np.int64)
     fit, rmse = C.c_double(), C.c_double()
     si = _f32(src_int) if src_int is not None else None
     ti = _f32(tgt_int) if tgt_int is not None else None
-    lib.oracle_register(_p(src), _p(si), C.c_int(len(src)), _p(tgt), _p(ti), C.c_int(len(tgt)), C.c_double(voxel_size),
+    lib.oracle_register_raw(_p(src), _p(sr), _p(si), C.c_int(len(src)), _p(tgt), _p(tr), _p(ti), C.c_int(len(tgt)), C.c_double(voxel_size),
                         C.c_double(global_dist_factor), C.c_double(local_dist_factor), C.c_int(int(have_colors)), C.c_uint64(seed),
                         C.c_uint32(job_id), C.c_int(ransac_max_iter), _p(T), C.byref(rmse), C.byref(fit), _p(Tr), _p(stats))
     return T.reshape(4, 4), rmse.value, fit.value, Tr.reshape(4, 4), stats
@@ -132,7 +137,8 @@ def localise_from_assignments(det_clouds, det_cols, mem_clouds, mem_cols, assns,
         src = (cd - detected_mean).astype(np.float32)
         tgt = (cm - memory_mean).astype(np.float32)
         T, rmse, fit, Tr, stats = register_point_clouds(src, ci_d, tgt, ci_m, voxel_size, global_dist_factor, local_dist_factor,
-                                                        seed=seed, job_id=job_base + a_i, ransac_max_iter=ransac_max_iter)
+                                                        seed=seed, job_id=job_base + a_i, ransac_max_iter=ransac_max_iter,
+                                                        src_raw=cd.astype(np.float32), tgt_raw=cm.astype(np.float32))
         G = T.copy()
         R = T[:3, :3]
         G[:3, 3] = T[:3, 3] + memory_mean - R @ detected_mean

@@ -60,7 +60,8 @@ def test_register_batch_vs_oracle(ctx, scene):
         src, tgt = (cd - dm).astype(np.float32), (cm - mm).astype(np.float32)
         si = np.concatenate([ro.intensity(f["clouds"][d][1]) for d, m in a])
         ti = np.concatenate([ro.intensity(w.colors[m]) for d, m in a])
-        T, rmse, fit, Tr, stats = ro.register_point_clouds(src, si, tgt, ti, 0.05, 1.5, 1.5, seed=77, job_id=100 + j)
+        T, rmse, fit, Tr, stats = ro.register_point_clouds(src, si, tgt, ti, 0.05, 1.5, 1.5, seed=77, job_id=100 + j,
+                                                           src_raw=cd.astype(np.float32), tgt_raw=cm.astype(np.float32))
         same = np.array_equal(stats, out["ransac_stats"][j])
         n_same_ransac += same
         print(f"job {j}: oracle stats {stats} gpu {out['ransac_stats'][j]} fit {fit:.4f}/{out['fitness'][j]:.4f} "
@@ -111,3 +112,57 @@ def test_evaluate_batch_vs_oracle(ctx, scene):
         assert abs(ef - fit[j]) <= 2.0 / (n - b) and abs(er - rmse[j]) < 1e-5, (j, ef, fit[j], er, rmse[j])
     assert fit[0] > fit[2] > fit[1]
     grid.close()
+
+
+@pytest.mark.parametrize("spacing", [2.5, 1.0])
+def test_register_cached_is_bit_identical(ctx, spacing):
+    """instance features (per-cloud normals / FPFH / gradients reused across jobs) must not change a single bit of the
+    results: far-apart instances are served from the cache, instances within the influence radius are recomputed"""
+    from ibloc_amd.registration import CloudBatch, instance_features_batch, register_batch
+    w = SynthWorld(9, pts_per_object=2500, E=1, D=8, seed=31, spacing=spacing)
+    rng = np.random.default_rng(32)
+    f = w.make_frame(rng, q=3, pts_per_object=2500, anchor=4)
+    ids = f["ids"]
+    det = CloudBatch.from_numpy([c[0] for c in f["clouds"]], [ro.intensity(c[1]) for c in f["clouds"]])
+    mem = CloudBatch.from_numpy(w.points, [ro.intensity(c) for c in w.colors])
+    js = [[0, -1, -1], [1, -1, -1], [0, 1, -1], [1, 0, -1], [0, 1, 2], [0, 1, -1], [2, 0, -1]]
+    jt = [[ids[0], -1, -1], [ids[1], -1, -1], [ids[0], ids[1], -1], [ids[1], ids[0], -1], [ids[0], ids[1], ids[2]],
+          [ids[0], ids[1], -1], [0, 8, -1]]
+    base = register_batch(ctx, det, mem, js, jt, 0.05, 1.5, 1.5, seed=5, job_id_base=7)
+    assert base["reuse"][0] == 0 and base["reuse"][2] < 2 * len(js)          # nothing cached; identical sides are computed once
+    fd = instance_features_batch(ctx, det, 0.05)
+    fm = instance_features_batch(ctx, mem, 0.05, grad_radius=2 * (0.05 * 1.5))
+    assert fd.bbox.shape == (3, 6) and np.all(fd.bbox[:, 3:] > fd.bbox[:, :3])
+    reused = []
+    for a, b in ((fd, None), (None, fm), (fd, fm)):
+        out = register_batch(ctx, det, mem, js, jt, 0.05, 1.5, 1.5, seed=5, job_id_base=7, det_features=a, mem_features=b)
+        for k in ("T", "rmse", "fitness", "T_ransac", "ransac_stats", "means"):
+            assert np.array_equal(base[k], out[k]), (k, spacing)
+        reused.append(out["reuse"])
+    print("reuse", spacing, reused)
+    assert reused[2][0] > 0                                 # single-instance sides always come from the cache
+    if spacing == 1.0:
+        assert reused[2][1] > 0                             # overlapping instances were recomputed in context
+    assert ctx.status() & 1 == 0
+
+
+def test_instance_features_equal_standalone_and_errors(ctx, scene):
+    from ibloc_amd import _lib
+    from ibloc_amd.registration import CloudBatch, instance_features_batch, normals_fpfh_batch, register_batch
+    w, f = scene
+    mem = CloudBatch.from_numpy(w.points[:4], [ro.intensity(c) for c in w.colors[:4]])
+    ft = instance_features_batch(ctx, mem, 0.05, grad_radius=0.15)
+    nrm, fp = normals_fpfh_batch(ctx, mem, 0.1, 30, 0.25, 100)
+    assert torch.equal(ft.normals[:mem.n], nrm) and torch.equal(ft.fpfh[:mem.n], fp)
+    for s in range(4):
+        p = w.points[s].astype(np.float32)
+        assert np.array_equal(ft.bbox[s, :3], p.min(0)) and np.array_equal(ft.bbox[s, 3:], p.max(0))
+    g = ro.color_gradient(w.points[1].astype(np.float32), nrm[mem.seg_off_host[1]:mem.seg_off_host[2], :3].cpu().numpy(),
+                          ro.intensity(w.colors[1]), 0.15, 30)
+    got = ft.grad[mem.seg_off_host[1]:mem.seg_off_host[2], :3].cpu().numpy()
+    assert np.allclose(got, g, atol=2e-4 * max(1.0, np.abs(g).max()))
+    det = CloudBatch.from_numpy([c[0] for c in f["clouds"]], [ro.intensity(c[1]) for c in f["clouds"]])
+    with pytest.raises(_lib.IblError):                      # features of another voxel size
+        register_batch(ctx, det, mem, [[0, -1, -1]], [[0, -1, -1]], 0.04, 1.5, 1.5, mem_features=ft)
+    with pytest.raises(_lib.IblError):                      # gradients of another radius
+        register_batch(ctx, det, mem, [[0, -1, -1]], [[0, -1, -1]], 0.05, 1.5, 1.0, mem_features=ft)
