@@ -293,7 +293,9 @@ typedef struct {
 int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
                                 int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh, float* grad4,
                                 float* bbox_host, void* stream);
-/* ibl_register_batch with the instance features of the detected pool and / or the memory pool (either may be NULL) */
+/* ibl_register_batch with the instance features of the detected pool and / or the memory pool (either may be NULL).
+ * reuse_stats_out [HOST][6] or NULL: points served by the instance features, points recomputed, recomputed groups,
+ * job sides, distinct (query instance, database instance) feature-matching pairs searched, pair uses by the jobs. */
 int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
                               int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
                               int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs, double voxel_size,

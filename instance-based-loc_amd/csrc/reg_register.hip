@@ -126,10 +126,12 @@ __global__ __launch_bounds__(256) void ibl_feat_assemble_kernel(const FeatCopy* 
                                                                 float* __restrict__ fpfh, float4* __restrict__ grad) {
     const FeatCopy c = copies[blockIdx.y];
     const int k = c.kind & 3;
-    const float* sf = src.fpfh[k] + (int64_t)c.src * 33;
-    float* df = fpfh + (int64_t)c.dst * 33;
-    const int nf = c.count * 33;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf; i += gridDim.x * 256) df[i] = sf[i];
+    if (fpfh) {
+        const float* sf = src.fpfh[k] + (int64_t)c.src * 33;
+        float* df = fpfh + (int64_t)c.dst * 33;
+        const int nf = c.count * 33;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nf; i += gridDim.x * 256) df[i] = sf[i];
+    }
     const float4* sn = src.normals[k] + c.src;
     const float4* sg = src.grad[k] + c.src;
     const bool want_grad = (c.kind & FEATCOPY_GRAD) != 0;
@@ -143,29 +145,37 @@ __global__ __launch_bounds__(256) void ibl_feat_assemble_kernel(const FeatCopy* 
 // feature matching: 1-NN in 33-d (fp32 fmaf chain k = 0..32, first minimum wins), both directions
 // grid (tiles, 2J): y < J: queries = source j, database = target j;  y >= J: the reverse
 // ------------------------------------------------------------------------------------------------
+// A job side is a concatenation of up to three instances, and the same (query instance, database instance) pair recurs in
+// many jobs of a frame (every assignment that contains both), so the search runs once per distinct PAIR and a job's
+// nearest neighbours are folded from its pairs in concatenation order with a strict '<' -- exactly the first minimum the
+// scan over the concatenated database finds.  Features are read in place (instance caches / recomputed groups).
 #define FT_TILE 32
-__global__ __launch_bounds__(256) void ibl_feat_nn_kernel(const float* __restrict__ feat, const int* __restrict__ job_off, int J,
-                                                          int* __restrict__ nn /* [N]: database-local index */) {
-    const int qs = blockIdx.y;
-    const int ds = qs < J ? qs + J : qs - J;
-    const int qb = job_off[qs], qe = job_off[qs + 1], db = job_off[ds], de = job_off[ds + 1];
-    const int q0 = qb + blockIdx.x * 256;
-    if (q0 >= qe) return;
+struct FeatPair { int qkind, qsrc, qcnt, dkind, dsrc, dcnt, out, pad; };     // kind: FeatSources index; src: point offset there
+struct SidePairs { int qcnt[3]; int dcnt[3]; int pair[3][3]; };              // per job side: slot sizes, pair ids (-1 = none)
+
+// grid (query tiles, pairs)
+__global__ __launch_bounds__(256) void ibl_feat_pair_nn_kernel(const FeatPair* __restrict__ pairs, FeatSources src, int* __restrict__ out_idx,
+                                                               float* __restrict__ out_d2) {
+    const FeatPair P = pairs[blockIdx.y];
+    const int q0 = blockIdx.x * 256;
+    if (q0 >= P.qcnt) return;
+    const float* __restrict__ qf = src.fpfh[P.qkind] + (int64_t)P.qsrc * 33;
+    const float* __restrict__ df = src.fpfh[P.dkind] + (int64_t)P.dsrc * 33;
     const int qi = q0 + threadIdx.x;
-    const bool valid = qi < qe;
+    const bool valid = qi < P.qcnt;
     float f[33];
     {
-        const float* src = feat + (int64_t)(valid ? qi : qe - 1) * 33;
+        const float* s = qf + (int64_t)(valid ? qi : P.qcnt - 1) * 33;
 #pragma unroll
-        for (int k = 0; k < 33; ++k) f[k] = src[k];
+        for (int k = 0; k < 33; ++k) f[k] = s[k];
     }
     __shared__ float tile[FT_TILE * 33];
     float best = INFINITY;
     int bj = 0;
-    for (int t0 = db; t0 < de; t0 += FT_TILE) {
-        const int nt = min(FT_TILE, de - t0);
+    for (int t0 = 0; t0 < P.dcnt; t0 += FT_TILE) {
+        const int nt = min(FT_TILE, P.dcnt - t0);
         __syncthreads();
-        for (int x = threadIdx.x; x < nt * 33; x += 256) tile[x] = feat[(int64_t)t0 * 33 + x];
+        for (int x = threadIdx.x; x < nt * 33; x += 256) tile[x] = df[(int64_t)t0 * 33 + x];
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
             // the partial sums of the chain are non-decreasing, so a target is abandoned as soon as no lane of the wave can
@@ -180,10 +190,35 @@ __global__ __launch_bounds__(256) void ibl_feat_nn_kernel(const float* __restric
             if (__ballot(acc < best) == 0ull) continue;
 #pragma unroll
             for (int k = 22; k < 33; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
-            if (acc < best) { best = acc; bj = t0 - db + t; }
+            if (acc < best) { best = acc; bj = t0 + t; }
         }
     }
-    if (valid) nn[qi] = bj;
+    if (valid) { out_idx[P.out + qi] = bj; out_d2[P.out + qi] = best; }
+}
+
+// thread per point of every job side: fold the pair results of its instance over the database instances in order
+__global__ __launch_bounds__(256) void ibl_feat_fold_kernel(const SidePairs* __restrict__ sides, const FeatPair* __restrict__ pairs,
+                                                            const int* __restrict__ pair_idx, const float* __restrict__ pair_d2,
+                                                            const int* __restrict__ job_off, int J, int* __restrict__ nn) {
+    const int n = job_off[2 * J];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int sgi = seg_of(job_off, 2 * J, i);
+    const SidePairs S = sides[sgi];
+    int local = i - job_off[sgi], a = 0;
+    while (a < 2 && local >= S.qcnt[a]) { local -= S.qcnt[a]; ++a; }
+    float best = INFINITY;
+    int bj = 0, dbase = 0;
+    for (int b = 0; b < 3; ++b) {
+        const int p = S.pair[a][b];
+        if (p >= 0) {
+            const int o = pairs[p].out + local;
+            const float d = pair_d2[o];
+            if (d < best) { best = d; bj = dbase + pair_idx[o]; }
+        }
+        dbase += S.dcnt[b];
+    }
+    nn[i] = bj;
 }
 
 // one block per job: mutual filter + ordered compaction; falls back to all source->target matches when fewer than
@@ -523,7 +558,11 @@ __global__ void ibl_icp_init_kernel(IcpState* __restrict__ st, int J, const Rans
     st[j] = s;
 }
 
-// nearest target point with d2 < r2 (fp32 distance on the float-rounded query); (d2, index) lexicographic minimum
+// nearest target point with d2 < r2 (fp32 distance on the float-rounded query); (d2, index) lexicographic minimum.
+// The row of cells through the query's own cell is scanned first: it nearly always holds the neighbour (or one almost as
+// close), after which the other rows are skipped unless their distance lower bound can still reach the best -- a row is
+// only skipped when the bound is strictly larger, so equal distances are always compared by index and the result does
+// not depend on the scan order.
 __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, float r2,
                                          float* d2out) {
     int reach = (int)ceilf(radius * sg.inv);
@@ -533,25 +572,32 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
     float bd = r2;
     const int x0 = max(cx - reach, 0), x1 = min(cx + reach, sg.nx - 1);
     const float csz = 1.0f / sg.inv, slack = 1e-4f * csz + 1e-6f;
-    if (x1 >= x0)
+    auto scan_row = [&](int z, int y) {
+        const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
+        const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+        for (int jj = b; jj < e; ++jj) {
+            const float4 p = g.sorted_pts[jj];
+            const float d2 = dist2f(qx, qy, qz, p.x, p.y, p.z);
+            if (d2 < bd) { bd = d2; best = g.order[jj]; }
+            else if (d2 == bd && best >= 0) { const int o = g.order[jj]; if (o < best) best = o; }
+        }
+    };
+    if (x1 >= x0) {
+        const bool centre = cz >= 0 && cz < sg.nz && cy >= 0 && cy < sg.ny;
+        if (centre) scan_row(cz, cy);
         for (int z = max(cz - reach, 0); z <= min(cz + reach, sg.nz - 1); ++z) {
-            // lower bound of the distance to any point of the row / cell: skip what cannot beat the current best
+            // lower bound of the distance to any point of the row: skip what cannot reach the current best
             const float zlo = sg.minz + (float)z * csz;
             const float gz = fmaxf((qz < zlo ? zlo - qz : (qz > zlo + csz ? qz - zlo - csz : 0.0f)) - slack, 0.0f);
             for (int y = max(cy - reach, 0); y <= min(cy + reach, sg.ny - 1); ++y) {
+                if (centre && z == cz && y == cy) continue;
                 const float ylo = sg.miny + (float)y * csz;
                 const float gy = fmaxf((qy < ylo ? ylo - qy : (qy > ylo + csz ? qy - ylo - csz : 0.0f)) - slack, 0.0f);
-                if (gz * gz + gy * gy >= bd) continue;
-                const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
-                const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-                for (int jj = b; jj < e; ++jj) {
-                    const float4 p = g.sorted_pts[jj];
-                    const float d2 = dist2f(qx, qy, qz, p.x, p.y, p.z);
-                    if (d2 < bd) { bd = d2; best = g.order[jj]; }
-                    else if (d2 == bd && best >= 0) { const int o = g.order[jj]; if (o < best) best = o; }
-                }
+                if (gz * gz + gy * gy > bd) continue;
+                scan_row(z, y);
             }
         }
+    }
     *d2out = bd;
     return best;
 }
@@ -785,6 +831,8 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     std::vector<GroupDesc> groups;
     std::vector<int> grp_off;
     std::vector<FeatCopy> copies;
+    std::vector<FeatPair> pairs;
+    std::vector<SidePairs> sides;
     if (colored) {
         IBL_ARENA(grad, float4, N + 1);
         IBL_ARENA(rs, RansacState, J);
@@ -794,9 +842,9 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         {
             // ---- normals + FPFH + colour gradients (instance cache / recomputed groups), then matching ----------
             ArenaMark m2(ctx);
-            float* fpfh; int* nn;
-            IBL_ARENA(fpfh, float, (int64_t)N * 33 + 64);
+            int* nn;
             IBL_ARENA(nn, int, N + 64);
+            int* pair_idx = nullptr; float* pair_d2 = nullptr; FeatPair* d_pairs = nullptr; SidePairs* d_sides = nullptr;
             const double grad_radius = max_dist_icp * 2.0;
             const ibl_instance_features* feat[2] = {det_features, mem_features};
             for (int pl = 0; pl < 2; ++pl) {
@@ -816,7 +864,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             // ---- plan: which instances of every job side keep their stand-alone features -------------------------
             std::map<std::array<int, 4>, int> gid[2];
             std::vector<std::array<int, 4>> gkeys[2];
-            struct SlotPlan { int dst, count, pool, seg, grp, pos; };
+            struct SlotPlan { int dst, count, pool, seg, grp, pos, side, kind, src; };
             std::vector<SlotPlan> slots;
             slots.reserve((size_t)6 * J);
             int64_t pts_cached = 0;
@@ -854,7 +902,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 for (int a = 0; a < 3; ++a) {
                     if (segs[a] < 0) continue;
                     const int cnt = off[segs[a] + 1] - off[segs[a]];
-                    slots.push_back({dst, cnt, pl, segs[a], dirty[a] ? g : -1, pos[a]});
+                    slots.push_back({dst, cnt, pl, segs[a], dirty[a] ? g : -1, pos[a], sgi, 0, 0});
                     if (!dirty[a]) pts_cached += cnt;
                     dst += cnt;
                 }
@@ -874,15 +922,61 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             const int Nd = grp_off[G];
             if (reuse_stats_out) { reuse_stats_out[0] = pts_cached; reuse_stats_out[1] = Nd; reuse_stats_out[2] = G; reuse_stats_out[3] = 2 * J; }
             copies.reserve(slots.size());
-            for (const SlotPlan& sp : slots) {
+            for (SlotPlan& sp : slots) {
+                if (sp.grp < 0) { sp.kind = sp.pool; sp.src = (sp.pool ? mem_off_host : det_off_host)[sp.seg]; }
+                else { sp.kind = 2; sp.src = grp_off[(sp.pool ? G0 : 0) + sp.grp] + sp.pos; }
                 if (sp.count <= 0) continue;
                 FeatCopy c;
-                c.dst = sp.dst; c.count = sp.count;
-                if (sp.grp < 0) { c.kind = sp.pool; c.src = (sp.pool ? mem_off_host : det_off_host)[sp.seg]; }
-                else { c.kind = 2; c.src = grp_off[(sp.pool ? G0 : 0) + sp.grp] + sp.pos; }
+                c.dst = sp.dst; c.count = sp.count; c.kind = sp.kind; c.src = sp.src;
                 if (sp.pool == 1) c.kind |= FEATCOPY_GRAD;
                 copies.push_back(c);
             }
+            // ---- feature matching plan: distinct (query instance, database instance) pairs -----------------------
+            std::vector<int> side_first(2 * J + 1, 0);      // slots are stored side by side, in slot order
+            for (const SlotPlan& sp : slots) ++side_first[sp.side + 1];
+            for (int i = 0; i < 2 * J; ++i) side_first[i + 1] += side_first[i];
+            std::map<std::array<int, 4>, int> pid;
+            sides.assign(2 * J, SidePairs{});
+            int64_t pair_pts = 0;
+            int max_q = 1;
+            for (int sgi = 0; sgi < 2 * J; ++sgi) {
+                const int other = sgi < J ? sgi + J : sgi - J;
+                SidePairs& S = sides[sgi];
+                for (int a = 0; a < 3; ++a) { S.qcnt[a] = S.dcnt[a] = 0; for (int b = 0; b < 3; ++b) S.pair[a][b] = -1; }
+                const int nq = side_first[sgi + 1] - side_first[sgi], nd = side_first[other + 1] - side_first[other];
+                for (int a = 0; a < nq; ++a) S.qcnt[a] = slots[side_first[sgi] + a].count;
+                for (int b = 0; b < nd; ++b) S.dcnt[b] = slots[side_first[other] + b].count;
+                for (int a = 0; a < nq; ++a)
+                    for (int b = 0; b < nd; ++b) {
+                        const SlotPlan& q = slots[side_first[sgi] + a];
+                        const SlotPlan& d = slots[side_first[other] + b];
+                        if (q.count <= 0 || d.count <= 0) continue;
+                        const std::array<int, 4> key = {q.kind, q.src, d.kind, d.src};
+                        auto it = pid.find(key);
+                        int id;
+                        if (it == pid.end()) {
+                            if (pair_pts + q.count > 0x7fffffff) return ibl_set_error(IBL_ERR_OVERFLOW, "feature matching: pair table exceeds 2^31 entries");
+                            id = (int)pairs.size();
+                            pid[key] = id;
+                            pairs.push_back({q.kind, q.src, q.count, d.kind, d.src, d.count, (int)pair_pts, 0});
+                            pair_pts += q.count;
+                            max_q = std::max(max_q, q.count);
+                        } else id = it->second;
+                        S.pair[a][b] = id;
+                    }
+            }
+            if (reuse_stats_out) {
+                int64_t uses = 0;
+                for (const SidePairs& S : sides)
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) uses += S.pair[a][b] >= 0 ? 1 : 0;
+                reuse_stats_out[4] = (int64_t)pairs.size();
+                reuse_stats_out[5] = uses;
+            }
+            IBL_ARENA(d_sides, SidePairs, 2 * J);
+            IBL_ARENA(d_pairs, FeatPair, (int64_t)pairs.size() + 1);
+            IBL_ARENA(pair_idx, int, pair_pts + 64);
+            IBL_ARENA(pair_d2, float, pair_pts + 64);
             {
                 ArenaMark md(ctx);
                 FeatSources src{};
@@ -916,16 +1010,26 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                     IBL_HIP_CHECK(hipMemcpyAsync(d_copies, copies.data(), sizeof(FeatCopy) * copies.size(), hipMemcpyHostToDevice, s));
                     for (size_t c0 = 0; c0 < copies.size(); c0 += 32768) {
                         const unsigned nc = (unsigned)std::min<size_t>(32768, copies.size() - c0);
-                        hipLaunchKernelGGL(ibl_feat_assemble_kernel, dim3(24, nc), dim3(256), 0, s, d_copies + c0, src, normals, fpfh, grad);
+                        hipLaunchKernelGGL(ibl_feat_assemble_kernel, dim3(8, nc), dim3(256), 0, s, d_copies + c0, src, normals, (float*)nullptr, grad);
                         IBL_LAUNCH_CHECK();
                     }
                 }
-                IBL_HIP_CHECK(hipStreamSynchronize(s));     // the scratch below the mark is reused by the matching kernels' successors
+                // matching reads the features in place (caches / recomputed groups), once per distinct pair
+                IBL_HIP_CHECK(hipMemcpyAsync(d_sides, sides.data(), sizeof(SidePairs) * sides.size(), hipMemcpyHostToDevice, s));
+                if (!pairs.empty()) {
+                    IBL_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(FeatPair) * pairs.size(), hipMemcpyHostToDevice, s));
+                    for (size_t p0 = 0; p0 < pairs.size(); p0 += 32768) {
+                        const unsigned np = (unsigned)std::min<size_t>(32768, pairs.size() - p0);
+                        hipLaunchKernelGGL(ibl_feat_pair_nn_kernel, dim3((max_q + 255) / 256, np), dim3(256), 0, s, d_pairs + p0, src, pair_idx, pair_d2);
+                        IBL_LAUNCH_CHECK();
+                    }
+                }
+                IBL_HIP_CHECK(hipStreamSynchronize(s));     // the group scratch is released here
             }
-            int max_seg = 1;
-            for (int i = 0; i < 2 * J; ++i) max_seg = std::max(max_seg, job_off[i + 1] - job_off[i]);
-            hipLaunchKernelGGL(ibl_feat_nn_kernel, dim3((max_seg + 255) / 256, 2 * J), dim3(256), 0, s, fpfh, d_job_off, J, nn);
-            IBL_LAUNCH_CHECK();
+            if (N > 0) {
+                hipLaunchKernelGGL(ibl_feat_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_sides, d_pairs, pair_idx, pair_d2, d_job_off, J, nn);
+                IBL_LAUNCH_CHECK();
+            }
             hipLaunchKernelGGL(ibl_mutual_kernel, dim3(J), dim3(256), 0, s, nn, d_job_off, J, 1, 9, corr, n_corr);
             IBL_LAUNCH_CHECK();
         }

@@ -144,7 +144,7 @@ def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_se
     pool segment ids (-1 padded).  det_features / mem_features: instance features of the two pools
     (instance_features_batch); the results do not depend on them, only the work does.  Returns dict of host arrays:
     T (J,4,4), rmse, fitness, means (J,2,3), T_ransac (J,4,4), ransac_stats (J,3), reuse (points served by the instance
-    features, points recomputed, recomputed groups, job sides)."""
+    features, points recomputed, recomputed groups, job sides, distinct matching pairs, pair uses)."""
     def pad(a):
         a = np.asarray(a, dtype=np.int32)
         if a.ndim == 1:
@@ -163,7 +163,7 @@ def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_se
     Tr = np.zeros((J, 16), dtype=np.float64)
     stats = np.zeros((J, 3), dtype=np.int64)
     flags = (REG_HAVE_COLORS if have_colors else 0) | (REG_CENTER if center else 0)
-    reuse = np.zeros(4, dtype=np.int64)
+    reuse = np.zeros(6, dtype=np.int64)
     df = det_features.as_struct() if det_features is not None else None
     mf = mem_features.as_struct() if mem_features is not None else None
     st = _lib.lib.ibl_register_batch_cached(ctx.handle, det.pts4.data_ptr(), det.seg_off.data_ptr(), det.seg_off_host.ctypes.data,
