@@ -169,29 +169,25 @@ __global__ __launch_bounds__(256) void ibl_feat_pair_nn_kernel(const FeatPair* _
 #pragma unroll
         for (int k = 0; k < 33; ++k) f[k] = s[k];
     }
-    __shared__ float tile[FT_TILE * 33];
+    // The database row is the same for every lane, so it is read through the scalar cache straight into SGPRs
+    // (s_load_dwordx*) and used as the scalar operand of the subtractions: no LDS staging, no barriers.
     float best = INFINITY;
     int bj = 0;
-    for (int t0 = 0; t0 < P.dcnt; t0 += FT_TILE) {
-        const int nt = min(FT_TILE, P.dcnt - t0);
-        __syncthreads();
-        for (int x = threadIdx.x; x < nt * 33; x += 256) tile[x] = df[(int64_t)t0 * 33 + x];
-        __syncthreads();
-        for (int t = 0; t < nt; ++t) {
-            // the partial sums of the chain are non-decreasing, so a target is abandoned as soon as no lane of the wave can
-            // still beat its running minimum (checked after each of the three 11-bin histogram blocks); the surviving
-            // distances are the complete k = 0..32 chains, bit-identical to the unpruned form
-            float acc = 0.0f;
+    for (int t = 0; t < P.dcnt; ++t) {
+        const float* __restrict__ row = df + (int64_t)t * 33;
+        // the partial sums of the chain are non-decreasing, so a target is abandoned as soon as no lane of the wave can
+        // still beat its running minimum (checked after bins 11 and 22); the surviving distances are the complete
+        // k = 0..32 chains, bit-identical to the unpruned form
+        float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
-            if (__ballot(acc < best) == 0ull) continue;
+        for (int k = 0; k < 11; ++k) { const float d = f[k] - row[k]; acc = __builtin_fmaf(d, d, acc); }
+        if (__ballot(acc < best) == 0ull) continue;
 #pragma unroll
-            for (int k = 11; k < 22; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
-            if (__ballot(acc < best) == 0ull) continue;
+        for (int k = 11; k < 22; ++k) { const float d = f[k] - row[k]; acc = __builtin_fmaf(d, d, acc); }
+        if (__ballot(acc < best) == 0ull) continue;
 #pragma unroll
-            for (int k = 22; k < 33; ++k) { const float d = f[k] - tile[t * 33 + k]; acc = __builtin_fmaf(d, d, acc); }
-            if (acc < best) { best = acc; bj = t0 + t; }
-        }
+        for (int k = 22; k < 33; ++k) { const float d = f[k] - row[k]; acc = __builtin_fmaf(d, d, acc); }
+        if (acc < best) { best = acc; bj = t; }
     }
     if (valid) { out_idx[P.out + qi] = bj; out_d2[P.out + qi] = best; }
 }

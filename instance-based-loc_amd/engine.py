@@ -7,6 +7,7 @@ Everything numerical runs in libibloc_hip.so; torch is used for device memory, s
 order-preserving boolean compaction only.
 """
 import os
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -70,6 +71,11 @@ class LocaliseEngine:
         self.ctx = memory.ctx
         self.assign_threads = assign_threads or min(os.cpu_count() or 1, 16)
         self.reuse_features = True      # False: every assignment recomputes its features (same results, the reference's schedule)
+        self._pool = ThreadPoolExecutor(max_workers=1)
+
+    def _det_features(self, clean, voxel_size):
+        torch.cuda.set_device(clean.pts4.device)          # worker thread: the current device is per thread
+        return instance_features_batch(self.ctx, clean, voxel_size)
 
     def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
                        fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, outlier_radius=0.05, outlier_nb_points=8,
@@ -125,9 +131,13 @@ class LocaliseEngine:
             if q_emb[f] < min(q_per_frame[f], 3):
                 raise AssertionError("fewer memory objects than the sub-volume dimension (reference asserts at similarity_volume.py:112)")
             aug_f[f, :q_emb[f]] = aug_h[row0[f]:row0[f] + q_emb[f]]
+        # The detections' instance features (normals / FPFH, once per frame batch instead of once per assignment) only need the
+        # cleaned clouds, so the GPU computes them while the host cores run the assignment search (both calls release the GIL).
+        det_feat_job = None
+        if self.reuse_features:
+            det_feat_job = self._pool.submit(self._det_features, clean, fpfh_voxel_size)
         assns = assign_batch(aug_f, q_emb, num_per_length, self.assign_threads)
-        if timings is not None:
-            timings.setdefault("assign_host_s", 0.0)
+        det_feat = det_feat_job.result() if det_feat_job is not None else None
         tick("assign")
         # ---- registration jobs (:1020-1106) ----------------------------------------------------------
         job_frame, job_src, job_tgt = [], [], []
@@ -140,10 +150,8 @@ class LocaliseEngine:
         if not job_frame:
             return results
         J = len(job_frame)
-        # instance features: the memory's are resident, the detections' are computed once per frame batch (not once per assignment)
+        # instance features: the memory's are resident (built on first use), the detections' were computed above
         mem_feat = mem.features(fpfh_voxel_size, fpfh_local_dist_factor) if self.reuse_features else None
-        det_feat = instance_features_batch(self.ctx, clean, fpfh_voxel_size) if self.reuse_features else None
-        tick("features")
         reg = register_batch(self.ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
                              fpfh_local_dist_factor, seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter,
                              have_colors=True, center=True, det_features=det_feat, mem_features=mem_feat)
