@@ -328,6 +328,40 @@ __device__ __forceinline__ bool ransac_edge_ok(const double* s, const double* d,
     return true;
 }
 
+// The same check for the flag kernel's first pass (every hypothesis, ~99 % rejected): squared edge lengths in fp32 against
+// edge_sim^2 with a 3e-6 guard band (the fp32 ratio is good to ~5e-7), no square roots.  Only a hypothesis with an edge
+// ratio inside the band -- or a zero-length edge -- falls back to the exact double-precision form above, so the verdict
+// is always the exact one.
+__device__ __forceinline__ bool ransac_edge_ok_draw(long long i, unsigned job_id, unsigned seed_lo, unsigned seed_hi,
+                                                    const float4* __restrict__ cp, int nc, double edge_sim, float e2_lo, float e2_hi) {
+    unsigned r[4];
+    philox4x32((unsigned)i, job_id, (unsigned)((unsigned long long)i >> 32), 0u, seed_lo, seed_hi, r);
+    float4 ps[3], pd[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int pick = (int)(((unsigned long long)r[t] * (unsigned long long)nc) >> 32);
+        ps[t] = cp[2 * pick]; pd[t] = cp[2 * pick + 1];
+    }
+    bool borderline = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 3; ++b) {
+            const float sx = ps[a].x - ps[b].x, sy = ps[a].y - ps[b].y, sz = ps[a].z - ps[b].z;
+            const float tx = pd[a].x - pd[b].x, ty = pd[a].y - pd[b].y, tz = pd[a].z - pd[b].z;
+            const float ds2 = sx * sx + sy * sy + sz * sz, dt2 = tx * tx + ty * ty + tz * tz;
+            if (ds2 < dt2 * e2_lo || dt2 < ds2 * e2_lo) return false;
+            if (!(ds2 > dt2 * e2_hi && dt2 > ds2 * e2_hi)) borderline = true;
+        }
+    if (!borderline) return true;
+    double s[9], d[9];
+    for (int t = 0; t < 3; ++t) {
+        s[3 * t] = ps[t].x; s[3 * t + 1] = ps[t].y; s[3 * t + 2] = ps[t].z;
+        d[3 * t] = pd[t].x; d[3 * t + 1] = pd[t].y; d[3 * t + 2] = pd[t].z;
+    }
+    return ransac_edge_ok(s, d, edge_sim);
+}
+
 // 3-point Kabsch + CorrespondenceCheckerBasedOnDistance
 __device__ inline bool ransac_fit_ok(const double* s, const double* d, double max_dist, double* T) {
     double sm[3] = {0, 0, 0}, dm[3] = {0, 0, 0};
@@ -378,6 +412,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
     __shared__ int cnt16[16];
     if (threadIdx.x < 16) cnt16[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
+    const float e2 = (float)(edge_sim * edge_sim), e2_lo = e2 * (1.0f - 3e-6f), e2_hi = e2 * (1.0f + 3e-6f);
     for (int sub = 0; sub < 4; ++sub) {
         __syncthreads();
         if (threadIdx.x == 0) nsurv = 0;
@@ -386,11 +421,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
             const int slot = blockIdx.x * RANSAC_CHUNK + sub * 1024 + r * 256 + threadIdx.x;
             const long long i = next_i + slot;
             bool ok = false;
-            if (job_on && i < est_k && i < max_iter) {
-                double sp[9], dp[9];
-                ransac_draw(i, job_id, seed_lo, seed_hi, c, nc, sp, dp);
-                ok = ransac_edge_ok(sp, dp, edge_sim);
-            }
+            if (job_on && i < est_k && i < max_iter) ok = ransac_edge_ok_draw(i, job_id, seed_lo, seed_hi, c, nc, edge_sim, e2_lo, e2_hi);
             const unsigned long long m = __ballot(ok);
             int base = 0;
             if (lane == 0 && m) base = atomicAdd(&nsurv, __popcll(m));
