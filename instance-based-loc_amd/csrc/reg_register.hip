@@ -629,27 +629,48 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
     return best;
 }
 
-// grid (ICP_BPJ, J): correspondences under the current T and the normal-equation / Kabsch moments
-__global__ __launch_bounds__(256) void ibl_icp_step_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
+// Thread per source point of every job: nearest target point under the job's current T.  Split from the accumulation so
+// that this latency-bound neighbour walk runs with few registers (many waves per SIMD hide the dependent cell / point
+// loads) while the fp64 normal equations run in their own kernel on coalesced inputs.
+__global__ __launch_bounds__(256) void ibl_icp_nn_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ job_off, int J,
+                                                         const IcpState* __restrict__ st, float radius, float r2, int* __restrict__ nn_idx,
+                                                         float* __restrict__ nn_d2) {
+    const int ns = job_off[J];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const int j = seg_of(job_off, J, i);
+    const IcpState& S = st[j];
+    if (S.done) return;
+    const float4 s4 = pts[i];
+    double T[12], vs[3];
+    for (int t = 0; t < 12; ++t) T[t] = S.T[t];
+    xform_d(T, s4.x, s4.y, s4.z, vs);
+    float d2;
+    nn_idx[i] = nn_within(g, g.seg[J + j], (float)vs[0], (float)vs[1], (float)vs[2], radius, r2, &d2);
+    nn_d2[i] = d2;
+}
+
+// grid (ICP_BPJ, J): the normal-equation / Kabsch moments of the correspondences found by ibl_icp_nn_kernel
+__global__ __launch_bounds__(256) void ibl_icp_step_kernel(const float4* __restrict__ pts, const float4* __restrict__ normals,
                                                            const float4* __restrict__ grad, const int* __restrict__ job_off, int J,
-                                                           const IcpState* __restrict__ st, float radius, float r2, int colored,
+                                                           const IcpState* __restrict__ st, const int* __restrict__ nn_idx,
+                                                           const float* __restrict__ nn_d2, int colored,
                                                            double sl_g, double sl_p, double* __restrict__ partial /* [J][BPJ][NACC] */) {
     const int j = blockIdx.y;
     const IcpState& S = st[j];
     if (S.done) return;
     const int sb = job_off[j], se = job_off[j + 1];
-    const SegGrid sg = g.seg[J + j];
     double T[12];
     for (int t = 0; t < 12; ++t) T[t] = S.T[t];
     double acc[ICP_NACC];
     for (int t = 0; t < ICP_NACC; ++t) acc[t] = 0.0;
     for (int i = sb + blockIdx.x * 256 + threadIdx.x; i < se; i += ICP_BPJ * 256) {
+        const int tj = nn_idx[i];
+        if (tj < 0) continue;
+        const float d2 = nn_d2[i];
         const float4 s4 = pts[i];
         double vs[3];
         xform_d(T, s4.x, s4.y, s4.z, vs);
-        float d2;
-        const int tj = nn_within(g, sg, (float)vs[0], (float)vs[1], (float)vs[2], radius, r2, &d2);
-        if (tj < 0) continue;
         acc[27] += 1.0;
         acc[28] += (double)d2;
         const float4 t4 = pts[tj];
@@ -1131,16 +1152,20 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     }
     // ---- ICP ------------------------------------------------------------------------------------------
     {
-        double* partial;
+        double* partial; int* icp_nn; float* icp_d2;
         IBL_ARENA(partial, double, (int64_t)J * ICP_BPJ * ICP_NACC);
+        IBL_ARENA(icp_nn, int, Ns + 64);
+        IBL_ARENA(icp_d2, float, Ns + 64);
         hipLaunchKernelGGL(ibl_icp_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, is, J, rs, colored ? 0 : 1);
         IBL_LAUNCH_CHECK();
         const double lambda_geometric = 0.968;
         const int max_iter = 30;
         for (int it = 0; it <= max_iter; ++it) {
-            hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, gC, P, normals, grad, d_job_off, J, is,
-                               (float)max_dist_icp, (float)(max_dist_icp * max_dist_icp), colored ? 1 : 0, sqrt(lambda_geometric),
-                               sqrt(1.0 - lambda_geometric), partial);
+            hipLaunchKernelGGL(ibl_icp_nn_kernel, dim3((Ns + 255) / 256), dim3(256), 0, s, gC, P, d_job_off, J, is, (float)max_dist_icp,
+                               (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
+            IBL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, P, normals, grad, d_job_off, J, is, icp_nn, icp_d2,
+                               colored ? 1 : 0, sqrt(lambda_geometric), sqrt(1.0 - lambda_geometric), partial);
             IBL_LAUNCH_CHECK();
             hipLaunchKernelGGL(ibl_icp_update_kernel, dim3((J + 63) / 64), dim3(64), 0, s, is, J, d_job_off, partial, colored ? 1 : 0, max_iter,
                                1e-6, 1e-6);
