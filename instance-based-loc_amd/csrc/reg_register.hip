@@ -388,10 +388,11 @@ __device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned 
     return ransac_fit_ok(s, d, max_dist, T);
 }
 
-// grid (round / 4096, active jobs): each block walks 4096 consecutive hypotheses.  The cheap part (draw + edge-length
+// grid (round / RANSAC_CHUNK, active jobs): each block walks RANSAC_CHUNK consecutive hypotheses.  The cheap part (draw + edge-length
 // check, ~99 % rejected) runs on every lane; the survivors are compacted through LDS so that the expensive part
 // (fp64 Kabsch + distance check) runs on densely packed lanes.  `flags` is zeroed by the host before the launch.
-#define RANSAC_CHUNK 4096
+#define RANSAC_SUBS 1                      // 1024-hypothesis passes per block
+#define RANSAC_CHUNK (1024 * RANSAC_SUBS)
 __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
                                                               long long max_iter, double max_dist, double edge_sim, unsigned seed_lo,
@@ -409,11 +410,11 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
     const unsigned job_id = job_id_base + (unsigned)j;
     __shared__ int surv[1024];
     __shared__ int nsurv;
-    __shared__ int cnt16[16];
-    if (threadIdx.x < 16) cnt16[threadIdx.x] = 0;
+    __shared__ int cnt16[4 * RANSAC_SUBS];
+    if (threadIdx.x < 4 * RANSAC_SUBS) cnt16[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const float e2 = (float)(edge_sim * edge_sim), e2_lo = e2 * (1.0f - 3e-6f), e2_hi = e2 * (1.0f + 3e-6f);
-    for (int sub = 0; sub < 4; ++sub) {
+    for (int sub = 0; sub < RANSAC_SUBS; ++sub) {
         __syncthreads();
         if (threadIdx.x == 0) nsurv = 0;
         __syncthreads();
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
         }
     }
     __syncthreads();
-    if (threadIdx.x < 16) blk_cnt[j * nblk + blockIdx.x * 16 + threadIdx.x] = cnt16[threadIdx.x];
+    if (threadIdx.x < 4 * RANSAC_SUBS) blk_cnt[j * nblk + blockIdx.x * (4 * RANSAC_SUBS) + threadIdx.x] = cnt16[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned char* __restrict__ flags, const int* __restrict__ blk_off,
