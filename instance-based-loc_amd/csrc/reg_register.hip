@@ -740,17 +740,18 @@ __device__ inline bool solve6_d(double A[6][6], double* b, double* x) {
     return true;
 }
 
-// thread per job: finish the reduction, convergence test, Gauss-Newton / Kabsch update
-__global__ void ibl_icp_update_kernel(IcpState* __restrict__ st, int J, const int* __restrict__ job_off, const double* __restrict__ partial,
+// wave per job: finish the reduction, convergence test, Gauss-Newton / Kabsch update
+__global__ __launch_bounds__(64) void ibl_icp_update_kernel(IcpState* __restrict__ st, int J, const int* __restrict__ job_off, const double* __restrict__ partial,
                                       int colored, int max_iter, double rel_fitness, double rel_rmse) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= J) return;
-    IcpState S = st[j];
-    if (S.done) return;
+    const int j = blockIdx.x;             // one wavefront per job: lane t folds moment t over the blocks (in block order), lane 0 solves
+    if (st[j].done) return;
+    double mine = 0.0;
+    if (threadIdx.x < ICP_NACC)
+        for (int b = 0; b < ICP_BPJ; ++b) mine += partial[((int64_t)j * ICP_BPJ + b) * ICP_NACC + threadIdx.x];
     double a[ICP_NACC];
-    for (int t = 0; t < ICP_NACC; ++t) a[t] = 0.0;
-    for (int b = 0; b < ICP_BPJ; ++b)
-        for (int t = 0; t < ICP_NACC; ++t) a[t] += partial[((int64_t)j * ICP_BPJ + b) * ICP_NACC + t];
+    for (int t = 0; t < ICP_NACC; ++t) a[t] = __shfl(mine, t, 64);
+    if (threadIdx.x != 0) return;
+    IcpState S = st[j];
     const int ns = job_off[j + 1] - job_off[j];
     const double cnt = a[27], err2 = a[28];
     const double nf = ns > 0 ? cnt / (double)ns : 0.0, nr = cnt > 0 ? sqrt(err2 / cnt) : 0.0;
@@ -1168,7 +1169,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, P, normals, grad, d_job_off, J, is, icp_nn, icp_d2,
                                colored ? 1 : 0, sqrt(lambda_geometric), sqrt(1.0 - lambda_geometric), partial);
             IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL(ibl_icp_update_kernel, dim3((J + 63) / 64), dim3(64), 0, s, is, J, d_job_off, partial, colored ? 1 : 0, max_iter,
+            hipLaunchKernelGGL(ibl_icp_update_kernel, dim3(J), dim3(64), 0, s, is, J, d_job_off, partial, colored ? 1 : 0, max_iter,
                                1e-6, 1e-6);
             IBL_LAUNCH_CHECK();
         }
