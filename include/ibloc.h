@@ -278,7 +278,10 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
  * of A.  ibl_register_batch_cached uses the stored values for every instance whose bounding box is at least R
  * (plus a rounding margin) away from the other instances of its job side and recomputes the rest in the context of
  * the job's concatenation, which makes its results bit-identical to ibl_register_batch.
- *   normals4 [dev] N x float4, fpfh [dev] N x 33, grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
+ *   normals4 [dev] N x float4, fpfh [dev] N x 33 with every row in MATCHING ORDER (bin 11 b + c at position
+ *   3 * rank(c) + {b=1: 0, b=2: 1, b=0: 2}, rank over c = 5,4,6,3,7,2,8,1,9,0,10: the three histograms from their centre
+ *   bins outwards, interleaved -- the order in which the feature search sums its squared differences, so that its
+ *   early-abandon chain reads contiguously), grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
  *   gradients are recomputed per job), bbox [HOST] n_seg x 6 = (min xyz, max xyz) -- all written by
  *   ibl_instance_features_batch (the call synchronises); voxel_size / grad_radius: the parameters they hold for
  *   (grad_radius = 2 * voxel_size * local_dist_factor in register_point_clouds). */

@@ -12,7 +12,8 @@
 int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
                        int* status, hipStream_t s);
 int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
-                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s);
+                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int matching_order, int* status,
+                    hipStream_t s);
 int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,
                             unsigned char* keep, hipStream_t s);
 
@@ -113,7 +114,7 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
         IBL_ARENA(nbr_d2, float, (int64_t)n * max_nn_feature + 64);
         IBL_ARENA(nbr_cnt, int, n + 64);
         st = ibl_launch_fpfh(g, P, reinterpret_cast<const float4*>(normals4), seg_off_dev, n, radius_feature, max_nn_feature, spfh,
-                             nbr_idx, nbr_d2, nbr_cnt, fpfh, ctx->d_status, s);
+                             nbr_idx, nbr_d2, nbr_cnt, fpfh, 0, ctx->d_status, s);
         if (st) return st;
     }
     return IBL_OK;
@@ -145,7 +146,7 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
         IBL_ARENA(nbr_idx, int, (int64_t)n * 100 + 64);
         IBL_ARENA(nbr_d2, float, (int64_t)n * 100 + 64);
         IBL_ARENA(nbr_cnt, int, n + 64);
-        st = ibl_launch_fpfh(gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, ctx->d_status, s);
+        st = ibl_launch_fpfh(gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
         if (st) return st;
     }
     if (grad && gq1 > gq0) {

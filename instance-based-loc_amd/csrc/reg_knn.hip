@@ -567,6 +567,11 @@ __global__ __launch_bounds__(256) void ibl_spfh_kernel(BatchGrid g, const float4
     hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
 }
 
+// Position of histogram bin b in the "matching order" of the feature search (reg_register.hip, oracle_reg.c FEAT_ORDER: the
+// three histograms from their centre bins outwards, interleaved).  Instance features are stored in that order so that the
+// search reads the terms of its early-abandon chain contiguously.
+__constant__ int FEAT_POS[33] = {29, 23, 17, 11, 5, 2, 8, 14, 20, 26, 32, 27, 21, 15, 9, 3, 0, 6, 12, 18, 24, 30, 28, 22, 16, 10, 4, 1, 7, 13, 19, 25, 31};
+
 // FPFH(i) = 100 * sum_k SPFH(k)/d2_k / blocksum + SPFH(i)   (one wave per point, lanes = bins)
 __device__ __forceinline__ float spfh_value(const unsigned char* __restrict__ spfh_cnt, const int* __restrict__ nbr_cnt, int j, int b) {
     const int kj = nbr_cnt[j];
@@ -584,7 +589,7 @@ struct FpfhTile {
 
 __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __restrict__ spfh_cnt, const int* __restrict__ nbr_idx,
                                                        const float* __restrict__ nbr_d2, const int* __restrict__ nbr_cnt, int K, int n,
-                                                       float* __restrict__ fpfh) {
+                                                       int matching_order, float* __restrict__ fpfh) {
     __shared__ FpfhTile tiles[4];
     FpfhTile& T = tiles[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
             const double sc = sum != 0.0 ? 100.0 / sum : 0.0;
             out = (float)(acc * sc + (double)spfh_value(spfh_cnt, nbr_cnt, qi, lane));
         }
-        fpfh[(int64_t)qi * 33 + lane] = out;
+        fpfh[(int64_t)qi * 33 + (matching_order ? FEAT_POS[lane] : lane)] = out;
     }
 }
 
@@ -684,7 +689,8 @@ int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off
 }
 
 int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
-                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int* status, hipStream_t s) {
+                    unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int matching_order, int* status,
+                    hipStream_t s) {
     if (n <= 0) return IBL_OK;
     if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "fpfh: max_nn %d > 256 (SPFH histograms are stored as bytes)", max_nn);
     void* tok;
@@ -693,7 +699,7 @@ int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals
                        (float)(radius * radius), max_nn, spfh, nbr_idx, nbr_d2, nbr_cnt, status);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, fpfh);
+    hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, matching_order, fpfh);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
 }

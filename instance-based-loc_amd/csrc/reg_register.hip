@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void ibl_feat_assemble_kernel(const FeatCopy* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// feature matching: 1-NN in 33-d (fp32 fmaf chain k = 0..32, first minimum wins), both directions
+// feature matching: 1-NN in 33-d (fp32 fmaf chain over the bins in matching order, first minimum wins), both directions
 // grid (tiles, 2J): y < J: queries = source j, database = target j;  y >= J: the reverse
 // ------------------------------------------------------------------------------------------------
 // A job side is a concatenation of up to three instances, and the same (query instance, database instance) pair recurs in
@@ -169,25 +169,62 @@ __global__ __launch_bounds__(256) void ibl_feat_pair_nn_kernel(const FeatPair* _
 #pragma unroll
         for (int k = 0; k < 33; ++k) f[k] = s[k];
     }
-    // The database row is the same for every lane, so it is read through the scalar cache straight into SGPRs
-    // (s_load_dwordx*) and used as the scalar operand of the subtractions: no LDS staging, no barriers.
+    // Database rows go through LDS in tiles of FT_TILE rows (padded to 36 floats so that a row is read with broadcast
+    // ds_read_b128), shared by the four waves of the block and double-buffered: the next tile's global loads are issued
+    // before the current tile is searched and land in registers meanwhile.  (Reading the rows per wave through the scalar
+    // cache instead re-fetched every row from L2 once per wave: 5.7 TB/s of L2 traffic, which bound the kernel.)
+    __shared__ __attribute__((aligned(16))) float tiles[2][FT_TILE * 36];
+    constexpr int PRE = (FT_TILE * 33 + 255) / 256;
+    float pre[PRE];
+    auto fetch = [&](int t0) {
+        const int nt = min(FT_TILE, P.dcnt - t0) * 33;
+        const float* __restrict__ g = df + (int64_t)t0 * 33;
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) { const int e = threadIdx.x + 256 * i; pre[i] = e < nt ? g[e] : 0.0f; }
+    };
+    auto stash = [&](float* __restrict__ tile) {
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            if (e < FT_TILE * 33) { const int r = e / 33; tile[r * 36 + (e - r * 33)] = pre[i]; }
+        }
+    };
     float best = INFINITY;
     int bj = 0;
-    for (int t = 0; t < P.dcnt; ++t) {
-        const float* __restrict__ row = df + (int64_t)t * 33;
-        // the partial sums of the chain are non-decreasing, so a target is abandoned as soon as no lane of the wave can
-        // still beat its running minimum (checked after bins 11 and 22); the surviving distances are the complete
-        // k = 0..32 chains, bit-identical to the unpruned form
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { const float d = f[k] - row[k]; acc = __builtin_fmaf(d, d, acc); }
-        if (__ballot(acc < best) == 0ull) continue;
-#pragma unroll
-        for (int k = 11; k < 22; ++k) { const float d = f[k] - row[k]; acc = __builtin_fmaf(d, d, acc); }
-        if (__ballot(acc < best) == 0ull) continue;
-#pragma unroll
-        for (int k = 22; k < 33; ++k) { const float d = f[k] - row[k]; acc = __builtin_fmaf(d, d, acc); }
-        if (acc < best) { best = acc; bj = t; }
+    fetch(0);
+    stash(tiles[0]);
+    __syncthreads();
+    int cur = 0;
+    for (int t0 = 0; t0 < P.dcnt; t0 += FT_TILE, cur ^= 1) {
+        const bool more = t0 + FT_TILE < P.dcnt;
+        if (more) fetch(t0 + FT_TILE);
+        const float* __restrict__ tile = tiles[cur];
+        const int nt = min(FT_TILE, P.dcnt - t0);
+        for (int t = 0; t < nt; ++t) {
+            const float* __restrict__ row = tile + t * 36;
+            // Rows are stored in matching order (bins from the histogram centres outwards, FEAT_POS in reg_knn.hip), so the
+            // chain is k = 0..32 over contiguous memory.  Its partial sums are non-decreasing: a target is abandoned as soon
+            // as no lane of the wave can still beat its running minimum (checked after 4, 8, 12, 16 and 24 terms); the
+            // surviving distances are the complete chains, bit-identical to the unpruned form.
+            float acc = 0.0f;
+#define FT_STAGE(k0, k1)                                                                                       \
+            _Pragma("unroll") for (int k = k0; k < k1; ++k) { const float d = f[k] - row[k]; acc = __builtin_fmaf(d, d, acc); }
+            FT_STAGE(0, 4)
+            if (__ballot(acc < best) == 0ull) continue;
+            FT_STAGE(4, 8)
+            if (__ballot(acc < best) == 0ull) continue;
+            FT_STAGE(8, 12)
+            if (__ballot(acc < best) == 0ull) continue;
+            FT_STAGE(12, 16)
+            if (__ballot(acc < best) == 0ull) continue;
+            FT_STAGE(16, 24)
+            if (__ballot(acc < best) == 0ull) continue;
+            FT_STAGE(24, 33)
+#undef FT_STAGE
+            if (acc < best) { best = acc; bj = t0 + t; }
+        }
+        if (more) stash(tiles[cur ^ 1]);
+        __syncthreads();
     }
     if (valid) { out_idx[P.out + qi] = bj; out_d2[P.out + qi] = best; }
 }

@@ -99,6 +99,11 @@ def normals_fpfh_batch(ctx: RegContext, batch: CloudBatch, radius_normal, max_nn
     return normals[:batch.n], (fpfh[:batch.n] if fpfh is not None else None)
 
 
+# "matching order" of the 33 FPFH bins (histogram centres outwards, interleaved): instance features store their rows in this
+# order, the feature search sums its squared differences in it (csrc/reg_knn.hip FEAT_POS, oracle/oracle_reg.c FEAT_ORDER)
+FEAT_ORDER = np.array([b * 11 + c for c in (5, 4, 6, 3, 7, 2, 8, 1, 9, 0, 10) for b in (1, 2, 0)], dtype=np.int64)
+
+
 class _FeatStruct(C.Structure):
     _fields_ = [("normals4", C.c_void_p), ("fpfh", C.c_void_p), ("grad4", C.c_void_p), ("bbox", C.c_void_p),
                 ("voxel_size", C.c_double), ("grad_radius", C.c_double)]

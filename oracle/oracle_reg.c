@@ -382,9 +382,15 @@ void oracle_fpfh(const float* pts, const float* normals, int n, double radius, i
 /* ------------------------------------------------------------------------------------------ */
 /* feature matching: 33-d 1-NN both ways (fp32 chain), mutual filter                           */
 /* ------------------------------------------------------------------------------------------ */
+/* Summation order of the 33 squared differences ("matching order"): the bins of the three 11-bin histograms from their
+ * centres outwards, interleaved (angle histograms vary most around their middle bins), so that a partial sum grows as fast
+ * as possible and the product's early-abandon search drops a candidate after a few terms.  Any fixed order is a valid
+ * restatement of the reference's L2 distance (Open3D's KD-tree fixes none); oracle and product share this one so that
+ * every fp32 distance, and with it every nearest-neighbour decision, is bit-identical. */
+static const int FEAT_ORDER[33] = {16, 27, 5, 15, 26, 4, 17, 28, 6, 14, 25, 3, 18, 29, 7, 13, 24, 2, 19, 30, 8, 12, 23, 1, 20, 31, 9, 11, 22, 0, 21, 32, 10};
 static inline float feat_d2(const float* a, const float* b) {
     float acc = 0.0f;
-    for (int k = 0; k < 33; ++k) { float d = a[k] - b[k]; acc = fmaf(d, d, acc); }
+    for (int t = 0; t < 33; ++t) { const int k = FEAT_ORDER[t]; float d = a[k] - b[k]; acc = fmaf(d, d, acc); }
     return acc;
 }
 

@@ -153,7 +153,9 @@ def test_instance_features_equal_standalone_and_errors(ctx, scene):
     mem = CloudBatch.from_numpy(w.points[:4], [ro.intensity(c) for c in w.colors[:4]])
     ft = instance_features_batch(ctx, mem, 0.05, grad_radius=0.15)
     nrm, fp = normals_fpfh_batch(ctx, mem, 0.1, 30, 0.25, 100)
-    assert torch.equal(ft.normals[:mem.n], nrm) and torch.equal(ft.fpfh[:mem.n], fp)
+    from ibloc_amd.registration import FEAT_ORDER
+    assert torch.equal(ft.normals[:mem.n], nrm)
+    assert torch.equal(ft.fpfh[:mem.n], fp[:, torch.from_numpy(FEAT_ORDER).cuda()])      # rows are stored in matching order
     for s in range(4):
         p = w.points[s].astype(np.float32)
         assert np.array_equal(ft.bbox[s, :3], p.min(0)) and np.array_equal(ft.bbox[s, 3:], p.max(0))
