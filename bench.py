@@ -73,7 +73,9 @@ def build_workload(args, rank, device):
     mem_emb = np.concatenate(mem_emb).reshape(args.memory, args.views, -1)
     ctx = RegContext(int(args.arena_gb * (1 << 30)))
     mem = MemoryShard(ctx, list(mem_emb), world.points, colors=world.colors, device=device)
-    eng = LocaliseEngine(mem, enc)
+    # host cores are shared by the ranks of the node: the assignment search takes its share, at most 16 threads
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    eng = LocaliseEngine(mem, enc, assign_threads=max(1, min(16, cores // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))
     # query batches (distinct per step and per rank), device resident
     batches = []
     frng = np.random.default_rng(1000 + rank)
@@ -220,7 +222,7 @@ def main():
             traffic = json.load(open(pmc)).get("gemm_traffic_bytes_per_launch")
         roof = prof.roofline(traffic)
         cpu = None
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world_size == 1:       # the CPU leg is timed on rank 0 of the single-GPU run only
             v, cdt, threads = cpu_baseline(args, world, mem_emb, batches[args.warmup], args.cpu_frames)
             cpu = {"value": v, "unit": "query-frames/s", "cores": threads,
                    "kind": "port", "sample": f"{args.cpu_frames} frame(s) of the same workload, {cdt:.1f} s: torch-cpu fp32 ViT + "
