@@ -275,9 +275,10 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
  * the clouds are stored in (before the per-job centring) and the value at a point of instance A inside a
  * concatenation A+B+C equals its stand-alone value unless a point of B or C lies within the influence radius
  *     R = max(2 * 5 * voxel + 2 * voxel, grad_radius + 2 * voxel)
- * of A.  ibl_register_batch_cached uses the stored values for every instance whose bounding box is at least R
- * (plus a rounding margin) away from the other instances of its job side and recomputes the rest in the context of
- * the job's concatenation, which makes its results bit-identical to ibl_register_batch.
+ * of A.  ibl_register_batch_cached uses the stored values for every instance none of whose points is within R (plus a
+ * rounding margin) of a point of another instance of its job side -- bounding boxes first, then an exact point-set test
+ * on the device for the box pairs that are close -- and recomputes the rest in the context of the job's concatenation,
+ * which makes its results bit-identical to ibl_register_batch.
  *   normals4 [dev] N x float4, fpfh [dev] N x 33 with every row in MATCHING ORDER (bin 11 b + c at position
  *   3 * rank(c) + {b=1: 0, b=2: 1, b=0: 2}, rank over c = 5,4,6,3,7,2,8,1,9,0,10: the three histograms from their centre
  *   bins outwards, interleaved -- the order in which the feature search sums its squared differences, so that its

@@ -121,6 +121,58 @@ __global__ __launch_bounds__(256) void ibl_group_gather_kernel(const GroupDesc* 
     out[i] = p;
 }
 
+// Exact form of "instance B is within the influence radius of instance A": is any point of A closer than R to a point of B?
+// Bounding boxes alone call most neighbouring instances close (their boxes overlap in empty corners), which forces their
+// features to be recomputed in every job that contains both.  grid (NEAR_SPLIT, pairs): every block keeps the points of B
+// that lie within R of A's box in LDS and sweeps its share of A's points (those within R of B's box) over them.
+#define NEAR_SPLIT 8
+#define NEAR_CAP 5120
+struct NearPair { int pool, a, b, pad; float boxa[6], boxb[6]; };
+
+__device__ __forceinline__ float box_dist2(const float* bx, float x, float y, float z) {
+    const float dx = fmaxf(fmaxf(bx[0] - x, x - bx[3]), 0.0f), dy = fmaxf(fmaxf(bx[1] - y, y - bx[4]), 0.0f),
+                dz = fmaxf(fmaxf(bx[2] - z, z - bx[5]), 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+
+__global__ __launch_bounds__(256) void ibl_near_pair_kernel(const NearPair* __restrict__ pairs, const float4* __restrict__ det,
+                                                            const int* __restrict__ det_off, const float4* __restrict__ mem,
+                                                            const int* __restrict__ mem_off, float R2, int* __restrict__ flags) {
+    const NearPair P = pairs[blockIdx.y];
+    const float4* pool = P.pool ? mem : det;
+    const int* off = P.pool ? mem_off : det_off;
+    const int ab = off[P.a], ae = off[P.a + 1], bb = off[P.b], be = off[P.b + 1];
+    __shared__ float sx[NEAR_CAP], sy[NEAR_CAP], sz[NEAR_CAP];
+    __shared__ int nb, found;
+    if (threadIdx.x == 0) { nb = 0; found = 0; }
+    __syncthreads();
+    for (int i = bb + threadIdx.x; i < be; i += 256) {
+        const float4 p = pool[i];
+        if (box_dist2(P.boxa, p.x, p.y, p.z) < R2) {
+            const int pos = atomicAdd(&nb, 1);
+            if (pos < NEAR_CAP) { sx[pos] = p.x; sy[pos] = p.y; sz[pos] = p.z; }
+        }
+    }
+    __syncthreads();
+    const int n = nb;
+    if (n > NEAR_CAP) { if (threadIdx.x == 0) atomicOr(&flags[blockIdx.y], 1); return; }     // too many to hold: call it close
+    if (n == 0) return;
+    for (int i0 = ab + blockIdx.x * 256; i0 < ae; i0 += NEAR_SPLIT * 256) {
+        const int i = i0 + threadIdx.x;
+        bool hit = false;
+        if (i < ae) {
+            const float4 p = pool[i];
+            if (box_dist2(P.boxb, p.x, p.y, p.z) < R2)
+                for (int j = 0; j < n; ++j)
+                    if (dist2f(p.x, p.y, p.z, sx[j], sy[j], sz[j]) < R2) { hit = true; break; }
+        }
+        if (hit) found = 1;
+        __syncthreads();
+        if (found) break;
+    }
+    if (threadIdx.x == 0 && found) atomicOr(&flags[blockIdx.y], 1);
+}
+
 // grid (tiles, copies): contiguous block copies (an instance's features are contiguous at both ends)
 __global__ __launch_bounds__(256) void ibl_feat_assemble_kernel(const FeatCopy* __restrict__ copies, FeatSources src, float4* __restrict__ normals,
                                                                 float* __restrict__ fpfh, float4* __restrict__ grad) {
@@ -920,6 +972,8 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     std::vector<FeatCopy> copies;
     std::vector<FeatPair> pairs;
     std::vector<SidePairs> sides;
+    std::vector<NearPair> near;
+    std::vector<int> near_flag;
     if (colored) {
         IBL_ARENA(grad, float4, N + 1);
         IBL_ARENA(rs, RansacState, J);
@@ -948,6 +1002,52 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             // influence radius of a foreign point on the features of an instance (see ibloc.h) + rounding margin
             const double rn = voxel_size * 2, rf = voxel_size * 5;
             const double R = std::max(2 * rf + rn, grad_radius + rn) * 1.001 + 1e-4;
+            // ---- instances of one job side whose boxes are within R: decide exactly (point sets) on the device --------
+            auto box_gap2 = [&](int pl, int sa, int sb) {
+                const float* ba = feat[pl]->bbox + 6 * (size_t)sa;
+                const float* bb = feat[pl]->bbox + 6 * (size_t)sb;
+                double g2 = 0;
+                for (int c = 0; c < 3; ++c) {
+                    const double gap = std::max(0.0, std::max((double)ba[c] - (double)bb[3 + c], (double)bb[c] - (double)ba[3 + c]));
+                    g2 += gap * gap;
+                }
+                return g2;
+            };
+            std::map<std::array<int, 3>, int> near_id;
+            for (int sgi = 0; sgi < 2 * J; ++sgi) {
+                const int pl = sgi >= J ? 1 : 0, j = pl ? sgi - J : sgi;
+                if (!feat[pl]) continue;
+                const int* segs = pl ? jobs[j].tgt_seg : jobs[j].src_seg;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = a + 1; b < 3; ++b) {
+                        if (segs[a] < 0 || segs[b] < 0) continue;
+                        const std::array<int, 3> key = {pl, std::min(segs[a], segs[b]), std::max(segs[a], segs[b])};
+                        if (near_id.count(key) || box_gap2(pl, key[1], key[2]) >= R * R) continue;
+                        NearPair np;
+                        np.pool = pl; np.a = key[1]; np.b = key[2]; np.pad = 0;
+                        for (int c = 0; c < 6; ++c) { np.boxa[c] = feat[pl]->bbox[6 * (size_t)key[1] + c]; np.boxb[c] = feat[pl]->bbox[6 * (size_t)key[2] + c]; }
+                        near_id[key] = (int)near.size();
+                        near.push_back(np);
+                    }
+            }
+            near_flag.assign(near.size(), 0);
+            if (!near.empty()) {
+                ArenaMark mn(ctx);
+                NearPair* d_near; int* d_flags;
+                IBL_ARENA(d_near, NearPair, (int64_t)near.size());
+                IBL_ARENA(d_flags, int, (int64_t)near.size());
+                IBL_HIP_CHECK(hipMemcpyAsync(d_near, near.data(), sizeof(NearPair) * near.size(), hipMemcpyHostToDevice, s));
+                IBL_HIP_CHECK(hipMemsetAsync(d_flags, 0, sizeof(int) * near.size(), s));
+                const float Rf = nextafterf((float)R, INFINITY);
+                for (size_t p0 = 0; p0 < near.size(); p0 += 32768) {
+                    const unsigned np = (unsigned)std::min<size_t>(32768, near.size() - p0);
+                    hipLaunchKernelGGL(ibl_near_pair_kernel, dim3(NEAR_SPLIT, np), dim3(256), 0, s, d_near + p0, det, det_off_dev, mem, mem_off_dev,
+                                       Rf * Rf * 1.000001f, d_flags + p0);
+                    IBL_LAUNCH_CHECK();
+                }
+                IBL_HIP_CHECK(hipMemcpyAsync(near_flag.data(), d_flags, sizeof(int) * near.size(), hipMemcpyDeviceToHost, s));
+                IBL_HIP_CHECK(hipStreamSynchronize(s));
+            }
             // ---- plan: which instances of every job side keep their stand-alone features -------------------------
             std::map<std::array<int, 4>, int> gid[2];
             std::vector<std::array<int, 4>> gkeys[2];
@@ -963,16 +1063,10 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 for (int a = 0; a < 3; ++a) {
                     if (segs[a] < 0) continue;
                     if (!feat[pl]) { dirty[a] = true; continue; }
-                    const float* ba = feat[pl]->bbox + 6 * (size_t)segs[a];
                     for (int b = 0; b < 3; ++b) {
                         if (b == a || segs[b] < 0) continue;
-                        const float* bb = feat[pl]->bbox + 6 * (size_t)segs[b];
-                        double g2 = 0;
-                        for (int c = 0; c < 3; ++c) {
-                            const double gap = std::max(0.0, std::max((double)ba[c] - (double)bb[3 + c], (double)bb[c] - (double)ba[3 + c]));
-                            g2 += gap * gap;
-                        }
-                        if (g2 < R * R) dirty[a] = true;
+                        const auto it = near_id.find({pl, std::min(segs[a], segs[b]), std::max(segs[a], segs[b])});
+                        if (it != near_id.end() && near_flag[it->second]) dirty[a] = true;
                     }
                 }
                 std::array<int, 4> key = {pl, -1, -1, -1};
