@@ -194,7 +194,7 @@ def main():
         run_step(eng, batches[i], args)
     barrier()
     from ibloc_amd import prof
-    prof.reset()
+    prof.reset(enable=os.environ.get("IBL_BENCH_NOPROF", "") == "")
     timings = {}
     t0 = time.perf_counter()
     ok = 0
