@@ -357,6 +357,8 @@ __global__ __launch_bounds__(256) void ibl_mutual_kernel(const int* __restrict__
 // ------------------------------------------------------------------------------------------------
 #define RANSAC_MAX_ROUND 262144
 #define RANSAC_FIRST_ROUND 4096
+#define RANSAC_TAIL_JOBS 8                 // with at most this many jobs left ...
+#define RANSAC_TAIL_ROUND (1 << 20)        // ... a round walks this many hypotheses per job
 
 struct RansacState {
     double best_T[16];
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
                                                               unsigned char* __restrict__ flags /* [J][round] */,
                                                               int* __restrict__ blk_cnt /* [J][round/256] */,
                                                               const int* __restrict__ active /* job ids still running */) {
-    const int j = active[blockIdx.y];
+    const int a = blockIdx.y, j = active[a];        // per-round tables are indexed by the job's slot in the active list
     const int nblk = round_size / 256;
     const RansacState& S = st[j];
     const long long next_i = S.next_i, est_k = S.est_k;
@@ -525,29 +527,28 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
             double sp[9], dp[9], T[16];
             ransac_draw(next_i + slot, job_id, seed_lo, seed_hi, c, nc, sp, dp);
             if (ransac_fit_ok(sp, dp, max_dist, T)) {
-                flags[(int64_t)j * round_size + slot] = 1;
+                flags[(int64_t)a * round_size + slot] = 1;
                 atomicAdd(&cnt16[(slot - blockIdx.x * RANSAC_CHUNK) >> 8], 1);
             }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 4 * RANSAC_SUBS) blk_cnt[j * nblk + blockIdx.x * (4 * RANSAC_SUBS) + threadIdx.x] = cnt16[threadIdx.x];
+    if (threadIdx.x < 4 * RANSAC_SUBS) blk_cnt[a * nblk + blockIdx.x * (4 * RANSAC_SUBS) + threadIdx.x] = cnt16[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned char* __restrict__ flags, const int* __restrict__ blk_off,
-                                                                 int round_size, int* __restrict__ list /* slot ids, ordered */,
-                                                                 const int* __restrict__ active) {
-    const int j = active[blockIdx.y];
+                                                                 int round_size, int* __restrict__ list /* slot ids, ordered */) {
+    const int a = blockIdx.y;
     const int nblk = round_size / 256;
     const int slot = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = flags[(int64_t)j * round_size + slot] != 0;
+    const bool ok = flags[(int64_t)a * round_size + slot] != 0;
     __shared__ int wc[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long m = __ballot(ok);
     if (lane == 0) wc[wave] = __popcll(m);
     __syncthreads();
     if (ok) {
-        int pre = blk_off[j * nblk + blockIdx.x];
+        int pre = blk_off[a * nblk + blockIdx.x];
         for (int w = 0; w < wave; ++w) pre += wc[w];
         list[pre + __popcll(m & ((1ull << lane) - 1ull))] = slot;
     }
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned 
 
 // wave per survivor e in [0, total): job = the job whose offset range contains e
 __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
-                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr, int J,
+                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
+                                                               const int* __restrict__ active, int n_active,
                                                                double max_dist, double edge_sim, unsigned seed_lo, unsigned seed_hi,
                                                                unsigned job_id_base, int round_size, const int* __restrict__ blk_off,
                                                                const int* __restrict__ list, int total, int* __restrict__ e_inl,
@@ -564,12 +566,12 @@ __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const RansacState
     if (e >= total) return;
     const int lane = threadIdx.x & 63;
     const int nblk = round_size / 256;
-    int lo = 0, hi = J;                       // largest j with blk_off[j * nblk] <= e
+    int lo = 0, hi = n_active;                // largest active slot a with blk_off[a * nblk] <= e
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (blk_off[mid * nblk] <= e) lo = mid; else hi = mid;
     }
-    const int j = lo;
+    const int j = active[lo];
     const long long i = st[j].next_i + list[e];
     const float4* c = cp + 2 * (int64_t)job_off[j];
     const int nc = n_corr[j];
@@ -598,12 +600,12 @@ __global__ __launch_bounds__(64) void ibl_ransac_fold_kernel(RansacState* __rest
                                                              const int* __restrict__ e_inl, const double* __restrict__ e_err2,
                                                              const double* __restrict__ e_T, int total, int* __restrict__ n_active,
                                                              const int* __restrict__ active, int* __restrict__ active_next) {
-    const int j = active[blockIdx.x];
+    const int a = blockIdx.x, j = active[a];
     const int lane = threadIdx.x;
     RansacState S = st[j];
     if (S.done) return;
     const int nblk = round_size / 256;
-    const int b = blk_off[j * nblk], e = (j + 1 < J) ? blk_off[(j + 1) * nblk] : total;
+    const int b = blk_off[a * nblk], e = blk_off[(a + 1) * nblk];      // the scan has one entry past the last slot (= total)
     const int nc = n_corr[j];
     bool stop = false;
     long long n_before_stop = 0;          // survivors with index < the stopping index in this round
@@ -1219,21 +1221,24 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             ArenaMark m3(ctx);
             const double max_dist = voxel_size * global_dist_factor;
             const int max_round = RANSAC_MAX_ROUND;
-            const int max_blk = max_round / 256;
+            // a round's tables hold (active jobs) x (round size) hypotheses; when only a few jobs are left (wrong assignments
+            // that never reach the confidence exit walk all 4 M), rounds grow to RANSAC_TAIL_ROUND so that they still fill the GPU
+            const int64_t cap_slots = std::max<int64_t>((int64_t)J * max_round, (int64_t)RANSAC_TAIL_JOBS * RANSAC_TAIL_ROUND);
+            const int64_t cap_blk = cap_slots / 256;
             float4* cp; unsigned char* flags; int *blk_cnt, *blk_off, *list, *n_active;
             IBL_ARENA(cp, float4, 2 * (int64_t)Ns + 2);
-            IBL_ARENA(flags, unsigned char, (int64_t)J * max_round);
-            IBL_ARENA(blk_cnt, int, (int64_t)J * max_blk + 1);
-            IBL_ARENA(blk_off, int, (int64_t)J * max_blk + 1);
+            IBL_ARENA(flags, unsigned char, cap_slots);
+            IBL_ARENA(blk_cnt, int, cap_blk + 1);
+            IBL_ARENA(blk_off, int, cap_blk + 1);
             IBL_ARENA(n_active, int, 64);
-            const int list_cap = (int)std::min<int64_t>((int64_t)J * max_round / 16 + 65536, (int64_t)1 << 27);
+            const int list_cap = (int)std::min<int64_t>(cap_slots / 16 + 65536, (int64_t)1 << 27);
             IBL_ARENA(list, int, list_cap);
             int* e_inl; double *e_err2, *e_T;
             IBL_ARENA(e_inl, int, list_cap);
             IBL_ARENA(e_err2, double, list_cap);
             IBL_ARENA(e_T, double, (int64_t)list_cap * 12);
             size_t tmp_bytes = 0;
-            IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, blk_cnt, blk_off, J * max_blk + 1, s));
+            IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, blk_cnt, blk_off, (int)(cap_blk + 1), s));
             unsigned char* tmp;
             IBL_ARENA(tmp, unsigned char, (int64_t)tmp_bytes + 256);
             hipLaunchKernelGGL(ibl_pack_corr_kernel, dim3(16, J), dim3(256), 0, s, P, d_job_off, J, corr, n_corr, cp);
@@ -1252,23 +1257,24 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             int round_size = RANSAC_FIRST_ROUND;
             int cur = 0;
             while (walked < ransac_max_iter && h_active > 0) {
+                if (h_active <= RANSAC_TAIL_JOBS && round_size == max_round) round_size = RANSAC_TAIL_ROUND;
                 const int nblk = round_size / 256;
-                // per-round tables are indexed by job id; jobs that are not launched must read as "no survivors"
-                IBL_HIP_CHECK(hipMemsetAsync(blk_cnt, 0, sizeof(int) * ((size_t)J * nblk + 1), s));
-                IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)J * round_size, s));
+                const int n_tab = h_active * nblk;          // tables are indexed by (slot in the active list, block)
+                IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)h_active * round_size, s));
                 hipLaunchKernelGGL(ibl_ransac_flag_kernel, dim3(round_size / RANSAC_CHUNK, h_active), dim3(256), 0, s, rs, cp, d_job_off, n_corr, (long long)ransac_max_iter,
                                    max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags, blk_cnt, active[cur]);
                 IBL_LAUNCH_CHECK();
-                IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, J * nblk + 1, s));
+                IBL_HIP_CHECK(hipMemsetAsync(blk_cnt + n_tab, 0, sizeof(int), s));
+                IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, n_tab + 1, s));
                 int total = 0;
-                IBL_HIP_CHECK(hipMemcpyAsync(&total, blk_off + (int64_t)J * nblk, sizeof(int), hipMemcpyDeviceToHost, s));
+                IBL_HIP_CHECK(hipMemcpyAsync(&total, blk_off + n_tab, sizeof(int), hipMemcpyDeviceToHost, s));
                 IBL_HIP_CHECK(hipStreamSynchronize(s));
                 if (total > list_cap) return ibl_set_error(IBL_ERR_OVERFLOW, "ransac: %d surviving hypotheses in one round exceed the list capacity %d", total, list_cap);
                 if (total > 0) {
-                    hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, h_active), dim3(256), 0, s, flags, blk_off, round_size, list, active[cur]);
+                    hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, h_active), dim3(256), 0, s, flags, blk_off, round_size, list);
                     IBL_LAUNCH_CHECK();
-                    hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3((total + 3) / 4), dim3(256), 0, s, rs, cp, d_job_off, n_corr, J, max_dist, 0.9,
-                                       (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total, e_inl, e_err2, e_T);
+                    hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3((total + 3) / 4), dim3(256), 0, s, rs, cp, d_job_off, n_corr, active[cur], h_active,
+                                       max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total, e_inl, e_err2, e_T);
                     IBL_LAUNCH_CHECK();
                 }
                 IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
