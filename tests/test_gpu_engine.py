@@ -74,3 +74,38 @@ def test_localise_batch_matches_oracle_and_ground_truth():
         n_correct += int(t_err < 0.6 and r_err < 0.3)
     assert n_correct >= 1
     ctx.close()
+
+
+def test_feature_reuse_does_not_change_results():
+    """LocaliseEngine.reuse_features (instance features + pair-level matching) against the reference's schedule
+    (every assignment recomputes its features): identical assignments, transforms and poses"""
+    import torch
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+    from ibloc_amd.registration import CloudBatch, RegContext
+    from ibloc_amd.synth import SynthWorld
+    w = SynthWorld(12, pts_per_object=2500, E=2, D=32, seed=61, spacing=1.6)      # close enough for recomputed groups
+    rng = np.random.default_rng(62)
+    frames = [w.make_frame(rng, q=3, pts_per_object=2500) for _ in range(3)]
+    ctx = RegContext(6 << 30)
+    mem = MemoryShard(ctx, list(w.embeddings), w.points, colors=w.colors)
+    clouds = [c[0] for f in frames for c in f["clouds"]]
+    ints = [intensity_from_colors(c[1]) for f in frames for c in f["clouds"]]
+    det = CloudBatch.from_numpy(clouds, ints)
+    emb = np.concatenate([f["det_emb"] for f in frames])
+    qs = [len(f["ids"]) for f in frames]
+    out = []
+    for reuse in (True, False):
+        eng = LocaliseEngine(mem, None)
+        eng.reuse_features = reuse
+        tm = {}
+        out.append((eng.localise_batch(det, qs, det_emb=emb, fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5,
+                                       fpfh_local_dist_factor=1.5, seed=3, timings=tm), tm["reuse"]))
+    (ra, reuse_a), (rb, reuse_b) = out
+    assert reuse_a[0] > 0 and reuse_b[0] == 0
+    for a, b in zip(ra, rb):
+        assert a.assignments == b.assignments and a.best == b.best
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.pose_corrected, b.pose_corrected)
+        for x, y in zip(a.records, b.records):
+            assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["ransac_stats"], y["ransac_stats"])
+            assert x["full_fitness"] == y["full_fitness"]
+    ctx.close()

@@ -168,3 +168,28 @@ def test_instance_features_equal_standalone_and_errors(ctx, scene):
         register_batch(ctx, det, mem, [[0, -1, -1]], [[0, -1, -1]], 0.04, 1.5, 1.5, mem_features=ft)
     with pytest.raises(_lib.IblError):                      # gradients of another radius
         register_batch(ctx, det, mem, [[0, -1, -1]], [[0, -1, -1]], 0.05, 1.5, 1.0, mem_features=ft)
+
+
+def test_instance_features_chunked_equals_single_pass(ctx):
+    """more than 2^20 points: ibl_instance_features_batch walks the clouds in chunks of whole clouds with rebased offsets;
+    every chunk must reproduce what one pass over its clouds gives"""
+    from ibloc_amd.registration import CloudBatch, FEAT_ORDER, instance_features_batch, normals_fpfh_batch
+    rng = np.random.default_rng(5)
+    w = SynthWorld(4, pts_per_object=6000, E=1, D=8, seed=41)
+    clouds, ints = [], []
+    for k in range(200):                                    # 200 clouds x 6000 points = 1.2 M points -> two chunks
+        p = w.points[k % 4] + rng.normal(0, 0.5, size=3)
+        clouds.append(p)
+        ints.append(ro.intensity(w.colors[k % 4]))
+    big = CloudBatch.from_numpy(clouds, ints)
+    assert big.n > (1 << 20)
+    ft = instance_features_batch(ctx, big, 0.05, grad_radius=0.15)
+    order = torch.from_numpy(FEAT_ORDER).cuda()
+    for lo, hi in ((0, 3), (172, 176), (197, 200)):         # first chunk, across the chunk boundary (cloud 174), last clouds
+        sub = CloudBatch.from_numpy(clouds[lo:hi], ints[lo:hi])
+        nrm, fp = normals_fpfh_batch(ctx, sub, 0.1, 30, 0.25, 100)
+        b, e = big.seg_off_host[lo], big.seg_off_host[hi]
+        assert torch.equal(ft.normals[b:e], nrm) and torch.equal(ft.fpfh[b:e], fp[:, order])
+        one = instance_features_batch(ctx, sub, 0.05, grad_radius=0.15)
+        assert torch.equal(ft.grad[b:e], one.grad[:sub.n]) and np.array_equal(ft.bbox[lo:hi], one.bbox)
+    assert ctx.status() & 1 == 0
