@@ -229,6 +229,22 @@ int ibl_reg_ctx_status(ibl_reg_ctx* ctx, int clear);
 /* Clouds are passed as batches of segments: pts4 [dev] N x float4 (x, y, z, intensity =
  * (r+g+b)/3), seg_off [dev] and [host] copies of the (n_seg + 1) int32 segment boundaries. */
 
+/* Depth image + instance masks -> one coloured cloud per mask.  Replaces
+ * get_mask_coloured_pointclouds_from_depth / get_coloured_pointcloud_from_depth (utils/depth_utils.py:176-206, 46-90)
+ * before their outlier step (-> ibl_radius_outlier_batch): the reference's centred pixel grid
+ *     x = linspace(-W/2, W/2, W)[col] * z / fx,   y = linspace(H/2, -H/2, H)[row] * z / fy,   z = depth / depth_factor
+ * (float32 linspace values, utils/depth_utils.py:57-67, whose `w, h` names are swapped), pixels with z == 0 or outside the
+ * mask dropped, row-major pixel order kept, intensity = mean of the float32 colours / 255.  The arithmetic type follows
+ * numpy's promotion of the reference's expressions: a float32 depth image stays in float32 throughout, an integer or
+ * float64 one promotes the products to float64 (then rounded to the float32 of the HBM layout).
+ *   depth [dev] H x W; depth_type IBL_DEPTH_F32 / IBL_DEPTH_U16 / IBL_DEPTH_F64; rgb [dev] H x W x 3 u8; masks [dev] n_masks x H x W u8
+ *   pts4 [dev] capacity x float4 (n_masks * H * W always suffices), seg_off_dev [dev] / seg_off_host [HOST] n_masks + 1
+ * The call synchronises (the cloud sizes are returned to the host). */
+enum { IBL_DEPTH_F32 = 0, IBL_DEPTH_U16 = 1, IBL_DEPTH_F64 = 2 };
+int ibl_unproject_masks(ibl_reg_ctx* ctx, const void* depth, int depth_type, const uint8_t* rgb, const uint8_t* masks, int n_masks,
+                        int H, int W, double fx, double fy, double depth_factor, float* pts4, int64_t capacity,
+                        int32_t* seg_off_dev, int32_t* seg_off_host, void* stream);
+
 /* keep[i] = 1 iff the point has more than nb_points points (itself included) within `radius` of its
  * own cloud.  Replaces PointCloud.remove_radius_outlier (object_memory/object_memory.py:994-995,
  * utils/depth_utils.py:87-88).  keep: [dev] N bytes. */

@@ -4,6 +4,8 @@
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include <vector>
 
 #include "ibloc.h"
@@ -206,6 +208,113 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
         if (st) return st;
         s0 = s1;
     }
+    IBL_HIP_CHECK(hipStreamSynchronize(s));
+    return IBL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// depth + masks -> coloured clouds (utils/depth_utils.py:46-90,176-206 before the outlier step)
+// ------------------------------------------------------------------------------------------------
+// depth_type: 0 float32 (numpy keeps float32 arithmetic: float32 array op python float), 1 uint16, 2 float64 (both float64)
+__device__ __forceinline__ double depth_at(const void* depth, int type, int64_t p) {
+    return type == 1 ? (double)reinterpret_cast<const unsigned short*>(depth)[p]
+                     : (type == 2 ? reinterpret_cast<const double*>(depth)[p] : (double)reinterpret_cast<const float*>(depth)[p]);
+}
+__device__ __forceinline__ double depth_z(const void* depth, int type, int64_t p, double factor) {
+    if (type == 0) return (double)(reinterpret_cast<const float*>(depth)[p] / (float)factor);
+    return depth_at(depth, type, p) / factor;
+}
+
+// flags[m * HW + p] = pixel p belongs to cloud m  (mask set and z != 0; z = depth / factor is non-zero iff it is after rounding)
+__global__ __launch_bounds__(256) void ibl_unproject_flag_kernel(const void* __restrict__ depth, int is_u16, const unsigned char* __restrict__ masks,
+                                                                 int64_t HW, int64_t total, double depth_factor, int* __restrict__ flags) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int64_t p = t % HW;
+    const double z = depth_z(depth, is_u16, p, depth_factor);
+    flags[t] = (masks[t] != 0 && z != 0.0) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ibl_unproject_write_kernel(const void* __restrict__ depth, int is_u16, const unsigned char* __restrict__ rgb,
+                                                                  const int* __restrict__ flags, const int* __restrict__ pos, int64_t HW, int W,
+                                                                  int64_t total, const float* __restrict__ hx, const float* __restrict__ vy,
+                                                                  double fx, double fy, double depth_factor, int64_t capacity,
+                                                                  float4* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total || !flags[t]) return;
+    const int o = pos[t];
+    if (o >= capacity) return;
+    const int64_t p = t % HW;
+    const int row = (int)(p / W), col = (int)(p - (int64_t)row * W);
+    const double z = depth_z(depth, is_u16, p, depth_factor);                     // depth_image / depth_factor
+    double x, y;
+    if (is_u16 == 0) {                                                            // float32 depth: numpy stays in float32
+        const float zf = (float)z;
+        x = (double)((hx[col] * zf) / (float)fx);
+        y = (double)((vy[row] * zf) / (float)fy);
+    } else {                                                                      // float32 grid * float64 depth / focal length
+        x = (double)hx[col] * z / fx;
+        y = (double)vy[row] * z / fy;
+    }
+    const float r = (float)rgb[3 * p] / 255.0f, g = (float)rgb[3 * p + 1] / 255.0f, b = (float)rgb[3 * p + 2] / 255.0f;
+    const double inten = ((double)r + (double)g + (double)b) / 3.0;
+    out[o] = make_float4((float)x, (float)y, (float)z, (float)inten);
+}
+
+// np.linspace(start, stop, num, dtype=float32): float64 `i * step + start`, last element = stop, rounded to float32
+static void linspace_f32(double start, double stop, int num, std::vector<float>& out) {
+    out.resize(num);
+    if (num == 1) { out[0] = (float)start; return; }
+    const double step = (stop - start) / (double)(num - 1);
+    for (int i = 0; i < num; ++i) {
+        volatile double prod = (double)i * step;       // keep the product and the sum separate roundings, as numpy does
+        out[i] = (float)(prod + start);
+    }
+    out[num - 1] = (float)stop;
+}
+
+extern "C" int ibl_unproject_masks(ibl_reg_ctx* ctx, const void* depth, int depth_type, const uint8_t* rgb, const uint8_t* masks,
+                                   int n_masks, int H, int W, double fx, double fy, double depth_factor, float* pts4, int64_t capacity,
+                                   int32_t* seg_off_dev, int32_t* seg_off_host, void* stream) {
+    if (!ctx || !seg_off_dev || !seg_off_host || n_masks < 0 || (n_masks > 0 && (!depth || !rgb || !masks || !pts4)) || H <= 0 || W <= 0 || fx == 0 || fy == 0 ||
+        depth_factor == 0 || capacity < 0 || depth_type < 0 || depth_type > 2)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_unproject_masks: bad argument");
+    const int64_t HW = (int64_t)H * W, total = HW * n_masks;
+    if (total > 0x7fffffff) return ibl_set_error(IBL_ERR_ARG, "ibl_unproject_masks: n_masks * H * W exceeds 2^31");
+    hipStream_t s = (hipStream_t)stream;
+    seg_off_host[0] = 0;
+    if (n_masks == 0) { IBL_HIP_CHECK(hipMemsetAsync(seg_off_dev, 0, sizeof(int), s)); IBL_HIP_CHECK(hipStreamSynchronize(s)); return IBL_OK; }
+    ArenaMark mark(ctx);
+    std::vector<float> hx, vy;
+    linspace_f32(-(double)W / 2.0, (double)W / 2.0, W, hx);       // the reference's `horizontal_distance` (its h is the column count)
+    linspace_f32((double)H / 2.0, -(double)H / 2.0, H, vy);       // `vertical_distance`
+    float *d_hx, *d_vy; int *flags, *pos;
+    IBL_ARENA(d_hx, float, W);
+    IBL_ARENA(d_vy, float, H);
+    IBL_ARENA(flags, int, total + 1);
+    IBL_ARENA(pos, int, total + 1);
+    IBL_HIP_CHECK(hipMemcpyAsync(d_hx, hx.data(), sizeof(float) * W, hipMemcpyHostToDevice, s));
+    IBL_HIP_CHECK(hipMemcpyAsync(d_vy, vy.data(), sizeof(float) * H, hipMemcpyHostToDevice, s));
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(ibl_unproject_flag_kernel, dim3(nb), dim3(256), 0, s, depth, depth_type, masks, HW, total, depth_factor, flags);
+    IBL_LAUNCH_CHECK();
+    IBL_HIP_CHECK(hipMemsetAsync(flags + total, 0, sizeof(int), s));
+    size_t tmp_bytes = 0;
+    IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flags, pos, (int)(total + 1), s));
+    unsigned char* tmp;
+    IBL_ARENA(tmp, unsigned char, (int64_t)tmp_bytes + 256);
+    IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, pos, (int)(total + 1), s));
+    std::vector<int> off(n_masks + 1);
+    for (int m = 0; m <= n_masks; ++m)
+        IBL_HIP_CHECK(hipMemcpyAsync(&off[m], pos + (int64_t)m * HW, sizeof(int), hipMemcpyDeviceToHost, s));
+    IBL_HIP_CHECK(hipStreamSynchronize(s));
+    if (off[n_masks] > capacity)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_unproject_masks: %d points do not fit the output capacity %lld", off[n_masks], (long long)capacity);
+    for (int m = 0; m <= n_masks; ++m) seg_off_host[m] = off[m];
+    IBL_HIP_CHECK(hipMemcpyAsync(seg_off_dev, seg_off_host, sizeof(int) * (n_masks + 1), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ibl_unproject_write_kernel, dim3(nb), dim3(256), 0, s, depth, depth_type, rgb, flags, pos, HW, W, total, d_hx, d_vy, fx, fy,
+                       depth_factor, capacity, reinterpret_cast<float4*>(pts4));
+    IBL_LAUNCH_CHECK();
     IBL_HIP_CHECK(hipStreamSynchronize(s));
     return IBL_OK;
 }

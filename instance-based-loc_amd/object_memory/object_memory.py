@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
-from ibloc_amd.registration import CloudBatch, RegContext, radius_outlier_batch
+from ibloc_amd.registration import CloudBatch, RegContext, radius_outlier_batch, unproject_masks
 from ibloc_amd.utils.fpfh_register import Cloud
 
 from .object_info import ObjectInfo
@@ -35,19 +35,21 @@ def default_load_depth(path: str) -> np.ndarray:
     return np.asarray(Image.open(path))
 
 
-def coloured_pointcloud_from_depth(depth_image, rgb_image, fx, fy):
-    """utils/depth_utils.py:46-90 without the outlier step: centred pixel grid (note the reference's swapped w/h names),
-    drop z == 0, colours / 255."""
-    assert depth_image.shape[:2] == rgb_image.shape[:2], "Depth and RGB image dimensions do not match"
-    w, h = depth_image.shape
-    horizontal = np.tile(np.linspace(-h / 2, h / 2, h, dtype=np.float32), (w, 1))
-    vertical = np.tile(np.linspace(w / 2, -w / 2, w, dtype=np.float32).reshape(-1, 1), (1, h))
-    X = horizontal * depth_image / fx
-    Y = vertical * depth_image / fy
-    pts = np.stack([X, Y, depth_image], axis=2).reshape(-1, 3)
-    valid = pts[:, 2] != 0
-    cols = (rgb_image.astype(np.float32) / 255.0).reshape(-1, 3)[valid]
-    return pts[valid], cols
+def _compact(batch: CloudBatch, keep: torch.Tensor) -> CloudBatch:
+    """drop the points with keep == 0 (order preserved)"""
+    kb = keep.bool()
+    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=keep.device), torch.cumsum(kb.to(torch.int64), 0)])
+    off = csum[torch.from_numpy(batch.seg_off_host.astype(np.int64)).to(keep.device)].cpu().numpy().astype(np.int32)
+    return CloudBatch(batch.pts4[kb].contiguous(), off)
+
+
+def _select(batch: CloudBatch, order) -> CloudBatch:
+    """the clouds `order` of a batch, in that order"""
+    off = batch.seg_off_host
+    parts = [batch.pts4[off[i]:off[i + 1]] for i in order]
+    sizes = [int(off[i + 1] - off[i]) for i in order]
+    pts = torch.cat(parts).contiguous() if parts else batch.pts4[:0]
+    return CloudBatch(pts, np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32))
 
 
 class ObjectMemory():
@@ -112,18 +114,23 @@ class ObjectMemory():
             current_obj_grounded_img=imgs[i], current_obj_bounding_box=boxes[i], current_obj_mask=masks[i],
             current_obj_phrase=phrases[i], full_rgb_image=rgb, full_depth_image=depth, consider_floor=consider_floor,
             device=self.device).cpu()) for i in range(len(imgs))])
-        clouds = []
-        for m in masks:
-            m2 = np.asarray(m.cpu() if hasattr(m, "cpu") else m).reshape(depth.shape[:2])
-            pts, cols = coloured_pointcloud_from_depth((depth / depth_factor) * m2, rgb, self.camera_focal_lenth_x,
-                                                       self.camera_focal_lenth_y)
-            clouds.append((pts, cols))
-        if outlier_removal_config is not None and clouds:
-            b = CloudBatch.from_numpy([c[0] for c in clouds], device=self.device)
-            keep = radius_outlier_batch(self._ctx, b, outlier_removal_config["radius"], outlier_removal_config["radius_nb_points"])
-            keep = keep.cpu().numpy().astype(bool)
-            off = b.seg_off_host
-            clouds = [(c[0][keep[off[i]:off[i + 1]]], c[1][keep[off[i]:off[i + 1]]]) for i, c in enumerate(clouds)]
+        # depth + masks -> one coloured cloud per object, then radius outlier removal: both on the device
+        # (utils/depth_utils.py:176-206 + :87-88); the clouds stay in HBM as a CloudBatch
+        dev = torch.device(self.device if str(self.device) != "cuda" else "cuda:0")
+        m_t = torch.stack([torch.as_tensor(np.asarray(m.cpu() if hasattr(m, "cpu") else m)).reshape(depth.shape[:2]) for m in masks]) \
+            if len(masks) else torch.zeros((0,) + depth.shape[:2], dtype=torch.uint8)
+        d_np = np.ascontiguousarray(depth)
+        if d_np.dtype == np.uint16:
+            d_t = torch.from_numpy(d_np.view(np.int16)).to(dev).view(torch.uint16)
+        elif d_np.dtype == np.float32:
+            d_t = torch.from_numpy(d_np).to(dev)
+        else:
+            d_t = torch.from_numpy(d_np.astype(np.float64)).to(dev)
+        clouds = unproject_masks(self._ctx, d_t, torch.from_numpy(np.array(rgb, dtype=np.uint8)).to(dev), (m_t != 0).to(dev),
+                                 self.camera_focal_lenth_x, self.camera_focal_lenth_y, depth_factor)
+        if outlier_removal_config is not None and clouds.n > 0:
+            keep = radius_outlier_batch(self._ctx, clouds, outlier_removal_config["radius"], outlier_removal_config["radius_nb_points"])
+            clouds = _compact(clouds, keep)
         return phrases, embs, clouds
 
     def localise_detections(self, detected_embs, detected_clouds, outlier_removal_config=None, fpfh_global_dist_factor=2,
@@ -132,15 +139,24 @@ class ObjectMemory():
         clouds [(points, colors), ...] -> FrameResult."""
         if outlier_removal_config is None:
             outlier_removal_config = {"radius_nb_points": 8, "radius": 0.05}
-        order = list(range(len(detected_clouds)))
-        if len(detected_clouds) > max_detected_object_num:                       # :900-908 keep the largest, reorder
-            order = sorted(order, key=lambda i: len(detected_clouds[i][0]), reverse=True)[:max_detected_object_num]
+        if isinstance(detected_clouds, CloudBatch):
+            sizes = np.diff(detected_clouds.seg_off_host)
+            order = list(range(len(sizes)))
+            if len(order) > max_detected_object_num:                             # :900-908 keep the largest, reorder
+                order = sorted(order, key=lambda i: int(sizes[i]), reverse=True)[:max_detected_object_num]
+            det = detected_clouds if order == list(range(len(sizes))) else _select(detected_clouds, order)
+            n_det = len(order)
+        else:
+            order = list(range(len(detected_clouds)))
+            if len(detected_clouds) > max_detected_object_num:                   # :900-908 keep the largest, reorder
+                order = sorted(order, key=lambda i: len(detected_clouds[i][0]), reverse=True)[:max_detected_object_num]
+            clouds = [detected_clouds[i] for i in order]
+            det = CloudBatch.from_numpy([c[0] for c in clouds], [intensity_from_colors(c[1]) for c in clouds], device=self.device)
+            n_det = len(clouds)
         embs = np.asarray(detected_embs, dtype=np.float32)[order]
-        clouds = [detected_clouds[i] for i in order]
-        det = CloudBatch.from_numpy([c[0] for c in clouds], [intensity_from_colors(c[1]) for c in clouds], device=self.device)
         self._n_queries += 1
         eng = self._get_engine()
-        return eng.localise_batch(det, [len(clouds)], det_emb=embs, fpfh_voxel_size=fpfh_voxel_size,
+        return eng.localise_batch(det, [n_det], det_emb=embs, fpfh_voxel_size=fpfh_voxel_size,
                                   fpfh_global_dist_factor=fpfh_global_dist_factor, fpfh_local_dist_factor=fpfh_local_dist_factor,
                                   outlier_radius=outlier_removal_config["radius"], outlier_nb_points=outlier_removal_config["radius_nb_points"],
                                   seed=self.ransac_seed, job_id_base=16 * self._n_queries)[0]

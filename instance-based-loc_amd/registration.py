@@ -77,6 +77,34 @@ class CloudBatch:
         return CloudBatch(torch.from_numpy(p4).to(device), off)
 
 
+def unproject_masks(ctx: RegContext, depth: torch.Tensor, rgb: torch.Tensor, masks: torch.Tensor, fx: float, fy: float,
+                    depth_factor: float = 1.0) -> CloudBatch:
+    """One coloured cloud per instance mask from a depth image (get_mask_coloured_pointclouds_from_depth,
+    utils/depth_utils.py:176-206, before its outlier step).  depth (H, W) float32, float64 or uint16 (int16 storage is read as uint16), rgb (H, W, 3)
+    uint8, masks (n, H, W) bool / uint8 -- device tensors.  Returns the clouds as a CloudBatch (x, y, z, intensity)."""
+    dev = depth.device
+    assert depth.is_cuda and rgb.is_cuda and masks.is_cuda and depth.dim() == 2
+    H, W = depth.shape
+    if depth.dtype in (torch.uint16, torch.int16):         # int16 storage = the bits of a uint16 image
+        is_u16, d = 1, depth.contiguous()
+    elif depth.dtype == torch.float32:
+        is_u16, d = 0, depth.contiguous()                  # numpy keeps float32 arithmetic for a float32 depth image
+    else:
+        is_u16, d = 2, depth.to(torch.float64).contiguous()
+    rgb = rgb.to(torch.uint8).contiguous()
+    m = masks.reshape(-1, H, W).to(torch.uint8).contiguous()
+    n = m.shape[0]
+    assert rgb.shape == (H, W, 3)
+    cap = int(m.count_nonzero().item()) if n else 0           # a mask pixel yields at most one point
+    pts4 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
+    off_dev = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    off_host = np.zeros(n + 1, dtype=np.int32)
+    st = _lib.lib.ibl_unproject_masks(ctx.handle, d.data_ptr(), is_u16, rgb.data_ptr(), m.data_ptr(), n, H, W, float(fx), float(fy),
+                                      float(depth_factor), pts4.data_ptr(), cap, off_dev.data_ptr(), off_host.ctypes.data, _stream())
+    _lib.check(st, "ibl_unproject_masks")
+    return CloudBatch(pts4[:int(off_host[-1])].contiguous() if off_host[-1] != cap or cap == 0 else pts4, off_host)
+
+
 def radius_outlier_batch(ctx: RegContext, batch: CloudBatch, radius: float, nb_points: int) -> torch.Tensor:
     keep = torch.empty(max(batch.n, 1), dtype=torch.uint8, device=batch.pts4.device)
     st = _lib.lib.ibl_radius_outlier_batch(ctx.handle, batch.pts4.data_ptr(), batch.seg_off.data_ptr(),
