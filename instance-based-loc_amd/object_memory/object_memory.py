@@ -89,6 +89,46 @@ class ObjectMemory():
         self.memory.append(info)
         self._engine = None
 
+    # ---- persistence: the reference's pickle layout (object_memory.py:779-846) -----------------------------
+    def save_to_pkl(self, save_directory: str):
+        """(list of (ObjectInfo without its cloud, points (N, 3) f64, colors (N, 3) f64), same tuple for the floor slot) --
+        the layout `load` of either implementation reads."""
+        import copy
+        import pickle
+
+        def strip(info):
+            blank = copy.copy(info)
+            blank.pointcloud = None
+            blank.pcd = None
+            blank.pcd_colors = None
+            cols = info.pointcloud.colors
+            return (blank, np.asarray(info.pointcloud.points, dtype=np.float64),
+                    np.zeros((0, 3)) if cols is None else np.asarray(cols, dtype=np.float64))
+        if not self.memory:
+            raise RuntimeError("object memory is empty")
+        mem = [strip(o) for o in self.memory]
+        floors = strip(self.floors) if self.floors is not None else mem[-1]        # the reference stores the last object there
+        with open(save_directory, "wb") as f:
+            pickle.dump((mem, floors), f)
+
+    def load(self, load_directory: str):
+        """object_memory.py:831-846.  A pickle written by the reference resolves `object_memory.object_info.ObjectInfo` to this
+        package's class when it is first on sys.path; its attributes are taken as they are."""
+        import pickle
+        with open(load_directory, "rb") as f:
+            pklable_memory, pklable_floors = pickle.load(f)
+
+        def conv(info_tuple):
+            blank, pts, cols = info_tuple
+            blank.pointcloud = Cloud(pts, cols if len(cols) == len(pts) else None)
+            blank.embeddings = [np.asarray(e) for e in blank.embeddings]
+            if hasattr(blank, "_process_pointcloud"):
+                blank._process_pointcloud()
+            return blank
+        self.memory = [conv(t) for t in pklable_memory]
+        self.floors = conv(pklable_floors)
+        self._engine = None
+
     def _get_engine(self):
         if self._engine is None:
             if not self.memory:

@@ -112,3 +112,27 @@ def test_object_memory_localise_with_stub_finder(tmp_path):
                                 perform_semantic_icp=False, outlier_removal_config={"radius_nb_points": 2, "radius": 0.2})
     assert pose1.shape == (7,) and np.isfinite(pose1).all() and extra1[1] is None
     assert extra1[0][0][1] == 1                                          # matched the instance whose embedding was returned
+
+
+def test_object_memory_pickle_round_trip(tmp_path):
+    """save_to_pkl / load keep the reference's layout (object_memory.py:779-846): list of (ObjectInfo without cloud, points,
+    colors) + the floor slot; a memory loaded from it localises exactly like the one that wrote it"""
+    import pickle
+    from ibloc_amd.object_memory.object_memory import ObjectMemory
+    w = SynthWorld(4, pts_per_object=2500, E=2, D=32, seed=51)
+    rng = np.random.default_rng(53)
+    f = w.make_frame(rng, q=2, pts_per_object=2500, anchor=0)
+    dummy = lambda **kw: None
+    a = ObjectMemory("cuda", None, None, 300.0, 300.0, get_embeddings_func=dummy)
+    for j in range(w.M):
+        a.add_object(f"obj{j}", list(w.embeddings[j]), w.points[j], w.colors[j])
+    a.save_to_pkl(str(tmp_path / "mem.pkl"))
+    mem, floors = pickle.load(open(tmp_path / "mem.pkl", "rb"))
+    assert len(mem) == w.M and mem[0][0].pointcloud is None and mem[0][1].dtype == np.float64 and mem[0][1].shape == (2500, 3)
+    assert mem[2][0].names == ["obj2"] and len(mem[2][0].embeddings) == 2 and floors[1].shape == (2500, 3)
+    b = ObjectMemory("cuda", None, None, 300.0, 300.0, get_embeddings_func=dummy)
+    b.load(str(tmp_path / "mem.pkl"))
+    assert len(b.memory) == w.M and np.array_equal(b.memory[1].pointcloud.points, a.memory[1].pointcloud.points)
+    ra = a.localise_detections(f["det_emb"], f["clouds"], fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
+    rb = b.localise_detections(f["det_emb"], f["clouds"], fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
+    assert ra.assignments == rb.assignments and np.array_equal(ra.pose, rb.pose)
