@@ -579,13 +579,17 @@ __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const RansacState
     ransac_hypothesis(i, job_id_base + (unsigned)j, seed_lo, seed_hi, c, nc, max_dist, edge_sim, T);
     int inl = 0;
     double err2 = 0;
+    const double md2_hi = max_dist * max_dist * (1.0 + 1e-12);      // d2 >= this => sqrt(d2) >= max_dist for certain
     for (int k = lane; k < nc; k += 64) {
         const float4 ps = c[2 * k], q = c[2 * k + 1];
         double p[3];
         xform_d(T, ps.x, ps.y, ps.z, p);
         const double dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
-        const double dd = sqrt(dx * dx + dy * dy + dz * dz);
-        if (dd < max_dist) { ++inl; err2 += dd * dd; }
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < md2_hi) {          // most correspondences of most hypotheses are far outliers: no square root for them
+            const double dd = sqrt(d2);
+            if (dd < max_dist) { ++inl; err2 += dd * dd; }
+        }
     }
     inl = wave_sum_i(inl);
     err2 = wave_sum_d(err2);
