@@ -480,9 +480,9 @@ __device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned 
 }
 
 // grid (round / RANSAC_CHUNK, active jobs): each block walks RANSAC_CHUNK consecutive hypotheses.  The cheap part (draw + edge-length
-// check, ~99 % rejected) runs on every lane; the survivors are compacted through LDS so that the expensive part
-// (fp64 Kabsch + distance check) runs on densely packed lanes.  `flags` is zeroed by the host before the launch.
-#define RANSAC_SUBS 1                      // 1024-hypothesis passes per block
+// check, ~99 % rejected) runs on every lane; the survivors of the whole chunk are compacted through LDS so that the
+// expensive part (fp64 Kabsch + distance check) runs once, on densely packed lanes.  `flags` is zeroed by the host before the launch.
+#define RANSAC_SUBS 4                      // 1024-hypothesis passes per block (one Kabsch pass over all their survivors)
 #define RANSAC_CHUNK (1024 * RANSAC_SUBS)
 __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
@@ -499,37 +499,35 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
     const float4* c = cp + 2 * (int64_t)job_off[j];
     const int nc = n_corr[j];
     const unsigned job_id = job_id_base + (unsigned)j;
-    __shared__ int surv[1024];
+    __shared__ int surv[RANSAC_CHUNK];
     __shared__ int nsurv;
     __shared__ int cnt16[4 * RANSAC_SUBS];
     if (threadIdx.x < 4 * RANSAC_SUBS) cnt16[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nsurv = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const float e2 = (float)(edge_sim * edge_sim), e2_lo = e2 * (1.0f - 3e-6f), e2_hi = e2 * (1.0f + 3e-6f);
-    for (int sub = 0; sub < RANSAC_SUBS; ++sub) {
-        __syncthreads();
-        if (threadIdx.x == 0) nsurv = 0;
-        __syncthreads();
-        for (int r = 0; r < 4; ++r) {
-            const int slot = blockIdx.x * RANSAC_CHUNK + sub * 1024 + r * 256 + threadIdx.x;
-            const long long i = next_i + slot;
-            bool ok = false;
-            if (job_on && i < est_k && i < max_iter) ok = ransac_edge_ok_draw(i, job_id, seed_lo, seed_hi, c, nc, edge_sim, e2_lo, e2_hi);
-            const unsigned long long m = __ballot(ok);
-            int base = 0;
-            if (lane == 0 && m) base = atomicAdd(&nsurv, __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (ok) surv[base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
-        }
-        __syncthreads();
-        const int ns = nsurv;
-        for (int t = threadIdx.x; t < ns; t += 256) {
-            const int slot = surv[t];
-            double sp[9], dp[9], T[16];
-            ransac_draw(next_i + slot, job_id, seed_lo, seed_hi, c, nc, sp, dp);
-            if (ransac_fit_ok(sp, dp, max_dist, T)) {
-                flags[(int64_t)a * round_size + slot] = 1;
-                atomicAdd(&cnt16[(slot - blockIdx.x * RANSAC_CHUNK) >> 8], 1);
-            }
+    for (int r = 0; r < 4 * RANSAC_SUBS; ++r) {
+        const int slot = blockIdx.x * RANSAC_CHUNK + r * 256 + threadIdx.x;
+        const long long i = next_i + slot;
+        bool ok = false;
+        if (job_on && i < est_k && i < max_iter) ok = ransac_edge_ok_draw(i, job_id, seed_lo, seed_hi, c, nc, edge_sim, e2_lo, e2_hi);
+        const unsigned long long m = __ballot(ok);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&nsurv, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (ok) surv[base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+    }
+    __syncthreads();
+    // the survivors of the whole chunk (~1 %) go through the fp64 Kabsch together: a single, densely packed pass
+    const int ns = nsurv;
+    for (int t = threadIdx.x; t < ns; t += 256) {
+        const int slot = surv[t];
+        double sp[9], dp[9], T[16];
+        ransac_draw(next_i + slot, job_id, seed_lo, seed_hi, c, nc, sp, dp);
+        if (ransac_fit_ok(sp, dp, max_dist, T)) {
+            flags[(int64_t)a * round_size + slot] = 1;
+            atomicAdd(&cnt16[(slot - blockIdx.x * RANSAC_CHUNK) >> 8], 1);
         }
     }
     __syncthreads();
