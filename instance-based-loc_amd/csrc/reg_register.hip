@@ -479,11 +479,10 @@ __device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned 
     return ransac_fit_ok(s, d, max_dist, T);
 }
 
-// grid (round / RANSAC_CHUNK, active jobs): each block walks RANSAC_CHUNK consecutive hypotheses.  The cheap part (draw + edge-length
+// grid (round / (1024 RANSAC_SUBS), active jobs): each block walks 1024 RANSAC_SUBS consecutive hypotheses.  The cheap part (draw + edge-length
 // check, ~99 % rejected) runs on every lane; the survivors of the whole chunk are compacted through LDS so that the
 // expensive part (fp64 Kabsch + distance check) runs once, on densely packed lanes.  `flags` is zeroed by the host before the launch.
-#define RANSAC_SUBS 4                      // 1024-hypothesis passes per block (one Kabsch pass over all their survivors)
-#define RANSAC_CHUNK (1024 * RANSAC_SUBS)
+template <int RANSAC_SUBS>               // 1024-hypothesis passes per block (one Kabsch pass over all their survivors)
 __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
                                                               long long max_iter, double max_dist, double edge_sim, unsigned seed_lo,
@@ -491,6 +490,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
                                                               unsigned char* __restrict__ flags /* [J][round] */,
                                                               int* __restrict__ blk_cnt /* [J][round/256] */,
                                                               const int* __restrict__ active /* job ids still running */) {
+    constexpr int RANSAC_CHUNK = 1024 * RANSAC_SUBS;
     const int a = blockIdx.y, j = active[a];        // per-round tables are indexed by the job's slot in the active list
     const int nblk = round_size / 256;
     const RansacState& S = st[j];
@@ -1263,8 +1263,14 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 const int nblk = round_size / 256;
                 const int n_tab = h_active * nblk;          // tables are indexed by (slot in the active list, block)
                 IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)h_active * round_size, s));
-                hipLaunchKernelGGL(ibl_ransac_flag_kernel, dim3(round_size / RANSAC_CHUNK, h_active), dim3(256), 0, s, rs, cp, d_job_off, n_corr, (long long)ransac_max_iter,
-                                   max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags, blk_cnt, active[cur]);
+                if (round_size >= 16384)
+                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<16>, dim3(round_size / 16384, h_active), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
+                                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
+                                       blk_cnt, active[cur]);
+                else
+                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<4>, dim3(round_size / 4096, h_active), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
+                                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
+                                       blk_cnt, active[cur]);
                 IBL_LAUNCH_CHECK();
                 IBL_HIP_CHECK(hipMemsetAsync(blk_cnt + n_tab, 0, sizeof(int), s));
                 IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, n_tab + 1, s));
