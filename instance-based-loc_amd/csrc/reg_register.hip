@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void ibl_mutual_kernel(const int* __restrict__
 //           plus the count of survivors of every 256-hypothesis block
 //   scan    exclusive sum of the block counts (hipcub) -> ordered offsets
 //   scatter ordered list of surviving (job, hypothesis) ids
-//   score   one wavefront per survivor: recompute its transform, validate it on the correspondence set
+//   score   thread per survivor: its transform (once); then one wavefront per survivor: validate it on the correspondence set
 //   fold    one wavefront per job: walk the survivors in hypothesis order and reproduce the sequential
 //           "better result -> tighten est_k" bookkeeping of the reference loop exactly
 // Correspondences are packed as (source xyz, target xyz) pairs so that a draw costs two 16-byte loads.
@@ -552,17 +552,15 @@ __global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned 
     }
 }
 
-// wave per survivor e in [0, total): job = the job whose offset range contains e
-__global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
-                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
-                                                               const int* __restrict__ active, int n_active,
-                                                               double max_dist, double edge_sim, unsigned seed_lo, unsigned seed_hi,
-                                                               unsigned job_id_base, int round_size, const int* __restrict__ blk_off,
-                                                               const int* __restrict__ list, int total, int* __restrict__ e_inl,
-                                                               double* __restrict__ e_err2, double* __restrict__ e_T) {
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+// thread per survivor e in [0, total): its transform, once (job = the active slot whose offset range contains e)
+__global__ __launch_bounds__(256) void ibl_ransac_transform_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
+                                                                   const int* __restrict__ job_off, const int* __restrict__ n_corr,
+                                                                   const int* __restrict__ active, int n_active, double max_dist, double edge_sim,
+                                                                   unsigned seed_lo, unsigned seed_hi, unsigned job_id_base, int round_size,
+                                                                   const int* __restrict__ blk_off, const int* __restrict__ list, int total,
+                                                                   int* __restrict__ e_job, double* __restrict__ e_T) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
-    const int lane = threadIdx.x & 63;
     const int nblk = round_size / 256;
     int lo = 0, hi = n_active;                // largest active slot a with blk_off[a * nblk] <= e
     while (hi - lo > 1) {
@@ -571,10 +569,27 @@ __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const RansacState
     }
     const int j = active[lo];
     const long long i = st[j].next_i + list[e];
+    double T[16];
+    ransac_hypothesis(i, job_id_base + (unsigned)j, seed_lo, seed_hi, cp + 2 * (int64_t)job_off[j], n_corr[j], max_dist, edge_sim, T);
+    e_job[e] = j;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) e_T[(int64_t)e * 12 + t] = T[t];
+}
+
+// wave per survivor: inliers and squared error of its transform over the job's correspondences
+__global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const float4* __restrict__ cp, const int* __restrict__ job_off,
+                                                               const int* __restrict__ n_corr, double max_dist, int total,
+                                                               const int* __restrict__ e_job, const double* __restrict__ e_T,
+                                                               int* __restrict__ e_inl, double* __restrict__ e_err2) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= total) return;
+    const int lane = threadIdx.x & 63;
+    const int j = e_job[e];
     const float4* c = cp + 2 * (int64_t)job_off[j];
     const int nc = n_corr[j];
-    double T[16];
-    ransac_hypothesis(i, job_id_base + (unsigned)j, seed_lo, seed_hi, c, nc, max_dist, edge_sim, T);
+    double T[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) T[t] = e_T[(int64_t)e * 12 + t];
     int inl = 0;
     double err2 = 0;
     const double md2_hi = max_dist * max_dist * (1.0 + 1e-12);      // d2 >= this => sqrt(d2) >= max_dist for certain
@@ -592,7 +607,6 @@ __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const RansacState
     inl = wave_sum_i(inl);
     err2 = wave_sum_d(err2);
     if (lane == 0) { e_inl[e] = inl; e_err2[e] = err2; }
-    if (lane < 12) e_T[(int64_t)e * 12 + lane] = T[lane];
 }
 
 // wave per job: fold the round's survivors in hypothesis order
@@ -1235,8 +1249,9 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             IBL_ARENA(n_active, int, 64);
             const int list_cap = (int)std::min<int64_t>(cap_slots / 16 + 65536, (int64_t)1 << 27);
             IBL_ARENA(list, int, list_cap);
-            int* e_inl; double *e_err2, *e_T;
+            int *e_inl, *e_job; double *e_err2, *e_T;
             IBL_ARENA(e_inl, int, list_cap);
+            IBL_ARENA(e_job, int, list_cap);
             IBL_ARENA(e_err2, double, list_cap);
             IBL_ARENA(e_T, double, (int64_t)list_cap * 12);
             size_t tmp_bytes = 0;
@@ -1281,8 +1296,12 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 if (total > 0) {
                     hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, h_active), dim3(256), 0, s, flags, blk_off, round_size, list);
                     IBL_LAUNCH_CHECK();
-                    hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3((total + 3) / 4), dim3(256), 0, s, rs, cp, d_job_off, n_corr, active[cur], h_active,
-                                       max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total, e_inl, e_err2, e_T);
+                    hipLaunchKernelGGL(ibl_ransac_transform_kernel, dim3((total + 255) / 256), dim3(256), 0, s, rs, cp, d_job_off, n_corr, active[cur],
+                                       h_active, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total,
+                                       e_job, e_T);
+                    IBL_LAUNCH_CHECK();
+                    hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3((total + 3) / 4), dim3(256), 0, s, cp, d_job_off, n_corr, max_dist, total, e_job,
+                                       e_T, e_inl, e_err2);
                     IBL_LAUNCH_CHECK();
                 }
                 IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
