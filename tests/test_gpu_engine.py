@@ -109,3 +109,46 @@ def test_feature_reuse_does_not_change_results():
             assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["ransac_stats"], y["ransac_stats"])
             assert x["full_fitness"] == y["full_fitness"]
     ctx.close()
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] sizes (M = 1000 instances x 5000 points, E = 4, Q = 7): properties that need no oracle run --
+    (1) batching: a frame localised alone equals the same frame inside a batch (same job ids -> same RANSAC draws);
+    (2) determinism: two runs give identical bits; (3) the recovered pose is the ground truth for most frames;
+    (4) the memory's resident instance features are built once and reused"""
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+    from ibloc_amd.registration import CloudBatch, RegContext
+    from ibloc_amd.synth import SynthWorld
+    w = SynthWorld(1000, pts_per_object=5000, E=4, D=64, seed=71)
+    rng = np.random.default_rng(72)
+    frames = [w.make_frame(rng, q=7, pts_per_object=5000) for _ in range(3)]
+    ctx = RegContext(20 << 30)
+    mem = MemoryShard(ctx, list(w.embeddings), w.points, colors=w.colors)
+    eng = LocaliseEngine(mem, None)
+
+    def run(fs, job_id_base):
+        det = CloudBatch.from_numpy([c[0] for f in fs for c in f["clouds"]], [intensity_from_colors(c[1]) for f in fs for c in f["clouds"]])
+        emb = np.concatenate([f["det_emb"] for f in fs])
+        tm = {}
+        res = eng.localise_batch(det, [len(f["ids"]) for f in fs], det_emb=emb, fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5,
+                                 fpfh_local_dist_factor=1.5, seed=11, job_id_base=job_id_base, timings=tm)
+        return res, tm
+    batch, tm = run(frames, 0)
+    again, _ = run(frames, 0)
+    n_jobs = [len(r.assignments) for r in batch]
+    ok = 0
+    for f, r, r2 in zip(frames, batch, again):
+        assert np.array_equal(r.pose, r2.pose) and r.assignments == r2.assignments                     # (2)
+        ok += int(np.linalg.norm(r.pose_corrected[:3] - f["pose"][:3, 3]) < 0.3)
+    assert ok >= 2                                                                                     # (3)
+    base = 0
+    for k, f in enumerate(frames):                                                                     # (1)
+        alone, _ = run([f], base)
+        assert alone[0].assignments == batch[k].assignments
+        assert np.array_equal(alone[0].pose, batch[k].pose)
+        for x, y in zip(alone[0].records, batch[k].records):
+            assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["ransac_stats"], y["ransac_stats"])
+        base += n_jobs[k]
+    assert tm["reuse"][0] > 0 and len(mem._features) == 1                                              # (4)
+    assert ctx.status() & 1 == 0
+    ctx.close()
