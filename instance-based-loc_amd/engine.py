@@ -160,10 +160,11 @@ class LocaliseEngine:
         tick("register")
         # global-frame transforms (:1096-1101)
         T = reg["T"]
+        means = reg["means"]
         G = T.copy()
-        for j in range(J):
-            R = T[j, :3, :3]
-            G[j, :3, 3] = T[j, :3, 3] + reg["means"][j, 1] - R @ reg["means"][j, 0]
+        Rm = T[:, :3, :3]
+        dm = means[:, 0]
+        G[:, :3, 3] = T[:, :3, 3] + means[:, 1] - ((Rm[:, :, 0] * dm[:, 0:1] + Rm[:, :, 1] * dm[:, 1:2]) + Rm[:, :, 2] * dm[:, 2:3])
         jb = [int(new_off_h[row0[f]]) for f in job_frame]
         je = [int(new_off_h[row0[f + 1]]) for f in job_frame]
         thr = eval_threshold if eval_threshold is not None else mem.eval_threshold
@@ -171,26 +172,29 @@ class LocaliseEngine:
         tick("evaluate")
         # ---- selection + pose (:1111-1131) -----------------------------------------------------------
         j = 0
+        picked = []                          # (frame, first job, best job) of the frames that have assignments
         for f in range(F):
             n_a = len(assns[f])
             if n_a == 0:
                 continue
-            recs = []
-            for k in range(n_a):
-                recs.append(dict(assn=assns[f][k], T=T[j + k], rmse=reg["rmse"][j + k], fitness=reg["fitness"][j + k],
-                                 full_rmse=full_rmse[j + k], full_fitness=full_fit[j + k], T_global=G[j + k],
-                                 detected_mean=reg["means"][j + k, 0], memory_mean=reg["means"][j + k, 1],
-                                 ransac_stats=reg["ransac_stats"][j + k]))
-            order = sorted(range(n_a), key=lambda k: recs[k]["full_fitness"], reverse=True)   # stable, like sorted() at :1111
-            best = order[0]
-            R = recs[best]["T"][:3, :3]
-            t = recs[best]["T"][:3, 3]
-            q = Rotation.from_matrix(R).as_quat()
-            last = recs[-1]
-            t_ref = t + last["memory_mean"] - R @ last["detected_mean"]           # stale means of the LAST assignment (:1127)
-            t_fix = t + recs[best]["memory_mean"] - R @ recs[best]["detected_mean"]
-            results[f] = FrameResult(np.concatenate((t_ref, q)), np.concatenate((t_fix, q)), assns[f], recs, best)
+            ff = full_fit[j:j + n_a]
+            best = max(range(n_a), key=lambda k: (ff[k], -k))      # first maximum == sorted(..., reverse=True)[0], stable (:1111)
+            picked.append((f, j, best))
             j += n_a
+        if picked:
+            quats = Rotation.from_matrix(np.stack([T[j0 + b, :3, :3] for _, j0, b in picked])).as_quat()
+        for (f, j0, best), q in zip(picked, quats if picked else []):
+            n_a = len(assns[f])
+            recs = [dict(assn=assns[f][k], T=T[j0 + k], rmse=reg["rmse"][j0 + k], fitness=reg["fitness"][j0 + k],
+                         full_rmse=full_rmse[j0 + k], full_fitness=full_fit[j0 + k], T_global=G[j0 + k],
+                         detected_mean=means[j0 + k, 0], memory_mean=means[j0 + k, 1], ransac_stats=reg["ransac_stats"][j0 + k])
+                    for k in range(n_a)]
+            R = T[j0 + best, :3, :3]
+            t = T[j0 + best, :3, 3]
+            last = j0 + n_a - 1
+            t_ref = t + means[last, 1] - R @ means[last, 0]                       # stale means of the LAST assignment (:1127)
+            t_fix = t + means[j0 + best, 1] - R @ means[j0 + best, 0]
+            results[f] = FrameResult(np.concatenate((t_ref, q)), np.concatenate((t_fix, q)), assns[f], recs, best)
         tick("select")
         if timings is not None:
             torch.cuda.synchronize()
