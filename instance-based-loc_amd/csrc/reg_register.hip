@@ -27,7 +27,7 @@
 int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, double voxel_size,
                           double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, float4* grad, hipStream_t s);
 
-#define ICP_BPJ 32       // blocks per job in the ICP / evaluation reductions
+#define ICP_BPJ 8        // blocks per job in the ICP / evaluation reductions (each ends in a 29-value fp64 block reduction)
 #define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
 
 // ------------------------------------------------------------------------------------------------
