@@ -487,20 +487,22 @@ __global__ __launch_bounds__(256) void ibl_attention_kernel(const u16* __restric
                 if (2 * s + 1 < NT) hi = *reinterpret_cast<const uint2*>(vp + 32);
                 uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&packed);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);     // O^T tile: rows = d, columns = q
             }
         }
-        // O layout: row = q = 4 g + r, col = d = fr.  Row sums live on lanes with (lane & 15) == q.
+        // O^T layout: row = d = 16 dt + 4 g + r, col = q = fr -> a lane owns four consecutive head dimensions of ONE query row
+        // (8-byte stores; the untransposed product left it with single bf16 elements of four rows) and that row's softmax
+        // sum is already on this lane (it was reduced over the lane groups above).
+        const int qg = qt * 16 + fr;
+        if (qg < T) {
+            const float inv = 1.0f / sum;
+            u16* orow = out + (tok0 + qg) * (int64_t)D + h * 64 + 4 * fg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = fg * 4 + r;
-            const float rs = __shfl(sum, q, 64);
-            const int qg = qt * 16 + q;
-            if (qg < T) {
-                const float inv = 1.0f / rs;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    out[(tok0 + qg) * (int64_t)D + h * 64 + dt * 16 + fr] = f2bf(o[dt][r] * inv);
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = (unsigned)f2bf(o[dt][0] * inv) | ((unsigned)f2bf(o[dt][1] * inv) << 16);
+                pk.y = (unsigned)f2bf(o[dt][2] * inv) | ((unsigned)f2bf(o[dt][3] * inv) << 16);
+                *reinterpret_cast<uint2*>(orow + dt * 16) = pk;
             }
         }
     }
