@@ -243,7 +243,7 @@ def main():
             "config": {"workload": f"{'C2' if args.memory == 1000 else 'T' if args.memory == 10000 else 'custom'}: {args.model} crops 224^2 "
                        f"(Q={args.q}), {args.memory}-instance memory (E={args.views}), FPFH+RANSAC+coloured ICP on {args.points}-pt clouds, "
                        "whole-memory evaluate", "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
-                       "points_per_object": args.points, "model": args.model, "parallelism": f"frames-dp{world_size}"},
+                       "points_per_object": args.points, "encoder": args.model, "parallelism": f"frames-dp{world_size}"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "stage_ms_per_step": {k: v / args.steps for k, v in timings.items() if isinstance(v, float)},
