@@ -206,18 +206,26 @@ struct FeatPair { int qkind, qsrc, qcnt, dkind, dsrc, dcnt, out, pad; };     // 
 struct SidePairs { int qcnt[3]; int dcnt[3]; int pair[3][3]; };              // per job side: slot sizes, pair ids (-1 = none)
 
 // grid (query tiles, pairs)
+// INDEXED: only the queries listed for the pair are searched (the target points that are some source point's nearest
+// neighbour -- the mutual filter reads no other target's result): need_pos = exclusive scan of the need flags over the
+// region of these pairs' outputs (which starts at out0), need_list = the flagged positions in order.
+template <bool INDEXED>
 __global__ __launch_bounds__(256) void ibl_feat_pair_nn_kernel(const FeatPair* __restrict__ pairs, FeatSources src, int* __restrict__ out_idx,
-                                                               float* __restrict__ out_d2) {
+                                                               float* __restrict__ out_d2, const int* __restrict__ need_pos,
+                                                               const int* __restrict__ need_list, int out0) {
     const FeatPair P = pairs[blockIdx.y];
     const int q0 = blockIdx.x * 256;
-    if (q0 >= P.qcnt) return;
+    int n_q = P.qcnt, l0 = 0;
+    if (INDEXED) { l0 = need_pos[P.out - out0]; n_q = need_pos[P.out - out0 + P.qcnt] - l0; }
+    if (q0 >= n_q) return;
     const float* __restrict__ qf = src.fpfh[P.qkind] + (int64_t)P.qsrc * 33;
     const float* __restrict__ df = src.fpfh[P.dkind] + (int64_t)P.dsrc * 33;
-    const int qi = q0 + threadIdx.x;
-    const bool valid = qi < P.qcnt;
+    const bool valid = q0 + (int)threadIdx.x < n_q;
+    const int qv = valid ? q0 + (int)threadIdx.x : n_q - 1;
+    const int qi = INDEXED ? need_list[l0 + qv] - (P.out - out0) : qv;          // local index of the query inside its instance
     float f[33];
     {
-        const float* s = qf + (int64_t)(valid ? qi : P.qcnt - 1) * 33;
+        const float* s = qf + (int64_t)qi * 33;
 #pragma unroll
         for (int k = 0; k < 33; ++k) f[k] = s[k];
     }
@@ -284,10 +292,9 @@ __global__ __launch_bounds__(256) void ibl_feat_pair_nn_kernel(const FeatPair* _
 // thread per point of every job side: fold the pair results of its instance over the database instances in order
 __global__ __launch_bounds__(256) void ibl_feat_fold_kernel(const SidePairs* __restrict__ sides, const FeatPair* __restrict__ pairs,
                                                             const int* __restrict__ pair_idx, const float* __restrict__ pair_d2,
-                                                            const int* __restrict__ job_off, int J, int* __restrict__ nn) {
-    const int n = job_off[2 * J];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+                                                            const int* __restrict__ job_off, int J, int i0, int i1, int* __restrict__ nn) {
+    const int i = i0 + blockIdx.x * 256 + threadIdx.x;
+    if (i >= i1) return;
     const int sgi = seg_of(job_off, 2 * J, i);
     const SidePairs S = sides[sgi];
     int local = i - job_off[sgi], a = 0;
@@ -304,6 +311,33 @@ __global__ __launch_bounds__(256) void ibl_feat_fold_kernel(const SidePairs* __r
         dbase += S.dcnt[b];
     }
     nn[i] = bj;
+}
+
+// thread per source point: flag the target point it matched as needed in every (target instance -> source instance) pair of
+// its job (the target's own nearest neighbour is folded over all source instances of the job)
+__global__ __launch_bounds__(256) void ibl_feat_need_kernel(const SidePairs* __restrict__ sides, const FeatPair* __restrict__ pairs,
+                                                            const int* __restrict__ job_off, int J, const int* __restrict__ nn, int out0,
+                                                            int* __restrict__ need) {
+    const int ns = job_off[J];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const int j = seg_of(job_off, J, i);
+    const SidePairs S = sides[j];                 // source side: dcnt = sizes of the target instances
+    int local = nn[i], b = 0;
+    if (local >= S.dcnt[0] + S.dcnt[1] + S.dcnt[2]) return;        // empty target side
+    while (b < 2 && local >= S.dcnt[b]) { local -= S.dcnt[b]; ++b; }
+    const SidePairs T = sides[J + j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int p = T.pair[b][a];
+        if (p >= 0) need[pairs[p].out - out0 + local] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void ibl_feat_need_list_kernel(const int* __restrict__ need, const int* __restrict__ pos, int n,
+                                                                 int* __restrict__ list) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n && need[e]) list[pos[e]] = e;
 }
 
 // one block per job: mutual filter + ordered compaction; falls back to all source->target matches when fewer than
@@ -1136,9 +1170,11 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             for (int i = 0; i < 2 * J; ++i) side_first[i + 1] += side_first[i];
             std::map<std::array<int, 4>, int> pid;
             sides.assign(2 * J, SidePairs{});
-            int64_t pair_pts = 0;
+            int64_t pair_pts = 0, pts0 = 0;     // outputs of the source-query pairs come first: [0, pts0)
+            int n_pairs0 = 0;
             int max_q = 1;
             for (int sgi = 0; sgi < 2 * J; ++sgi) {
+                if (sgi == J) { pts0 = pair_pts; n_pairs0 = (int)pairs.size(); }
                 const int other = sgi < J ? sgi + J : sgi - J;
                 SidePairs& S = sides[sgi];
                 for (int a = 0; a < 3; ++a) { S.qcnt[a] = S.dcnt[a] = 0; for (int b = 0; b < 3; ++b) S.pair[a][b] = -1; }
@@ -1215,19 +1251,57 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 }
                 // matching reads the features in place (caches / recomputed groups), once per distinct pair
                 IBL_HIP_CHECK(hipMemcpyAsync(d_sides, sides.data(), sizeof(SidePairs) * sides.size(), hipMemcpyHostToDevice, s));
-                if (!pairs.empty()) {
+                if (!pairs.empty() && N > 0) {
                     IBL_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(FeatPair) * pairs.size(), hipMemcpyHostToDevice, s));
-                    for (size_t p0 = 0; p0 < pairs.size(); p0 += 32768) {
-                        const unsigned np = (unsigned)std::min<size_t>(32768, pairs.size() - p0);
-                        hipLaunchKernelGGL(ibl_feat_pair_nn_kernel, dim3((max_q + 255) / 256, np), dim3(256), 0, s, d_pairs + p0, src, pair_idx, pair_d2);
+                    // (1) every source point's nearest target: source-query pairs, folded per job
+                    for (int p0 = 0; p0 < n_pairs0; p0 += 32768) {
+                        const unsigned np = (unsigned)std::min(32768, n_pairs0 - p0);
+                        hipLaunchKernelGGL(ibl_feat_pair_nn_kernel<false>, dim3((max_q + 255) / 256, np), dim3(256), 0, s, d_pairs + p0, src, pair_idx,
+                                           pair_d2, (const int*)nullptr, (const int*)nullptr, 0);
                         IBL_LAUNCH_CHECK();
                     }
+                    if (Ns > 0) {
+                        hipLaunchKernelGGL(ibl_feat_fold_kernel, dim3((Ns + 255) / 256), dim3(256), 0, s, d_sides, d_pairs, pair_idx, pair_d2, d_job_off,
+                                           J, 0, Ns, nn);
+                        IBL_LAUNCH_CHECK();
+                    }
+                    // (2) the reverse search only for the target points that were matched (a third to a half of them): flag,
+                    //     scan, list, search the listed queries; the other targets keep d2 = +inf and are never read
+                    const int n1 = (int)(pair_pts - pts0);
+                    const int n_pairs1 = (int)pairs.size() - n_pairs0;
+                    if (n1 > 0 && n_pairs1 > 0 && Ns > 0) {
+                        int *need, *need_pos, *need_list;
+                        IBL_ARENA(need, int, (int64_t)n1 + 1);
+                        IBL_ARENA(need_pos, int, (int64_t)n1 + 1);
+                        IBL_ARENA(need_list, int, (int64_t)n1 + 1);
+                        IBL_HIP_CHECK(hipMemsetAsync(need, 0, sizeof(int) * ((size_t)n1 + 1), s));
+                        IBL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(pair_d2 + pts0), 0x7f800000, (size_t)n1, s));
+                        IBL_HIP_CHECK(hipMemsetAsync(pair_idx + pts0, 0, sizeof(int) * (size_t)n1, s));
+                        hipLaunchKernelGGL(ibl_feat_need_kernel, dim3((Ns + 255) / 256), dim3(256), 0, s, d_sides, d_pairs, d_job_off, J, nn, (int)pts0, need);
+                        IBL_LAUNCH_CHECK();
+                        size_t tmp_bytes = 0;
+                        IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, need, need_pos, n1 + 1, s));
+                        unsigned char* tmp;
+                        IBL_ARENA(tmp, unsigned char, (int64_t)tmp_bytes + 256);
+                        IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, need, need_pos, n1 + 1, s));
+                        hipLaunchKernelGGL(ibl_feat_need_list_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, need, need_pos, n1, need_list);
+                        IBL_LAUNCH_CHECK();
+                        for (int p0 = 0; p0 < n_pairs1; p0 += 32768) {
+                            const unsigned np = (unsigned)std::min(32768, n_pairs1 - p0);
+                            hipLaunchKernelGGL(ibl_feat_pair_nn_kernel<true>, dim3((max_q + 255) / 256, np), dim3(256), 0, s, d_pairs + n_pairs0 + p0, src,
+                                               pair_idx, pair_d2, need_pos, need_list, (int)pts0);
+                            IBL_LAUNCH_CHECK();
+                        }
+                    }
+                    if (N > Ns) {
+                        hipLaunchKernelGGL(ibl_feat_fold_kernel, dim3((N - Ns + 255) / 256), dim3(256), 0, s, d_sides, d_pairs, pair_idx, pair_d2, d_job_off,
+                                           J, Ns, N, nn);
+                        IBL_LAUNCH_CHECK();
+                    }
+                } else if (N > 0) {
+                    IBL_HIP_CHECK(hipMemsetAsync(nn, 0, sizeof(int) * (size_t)N, s));
                 }
                 IBL_HIP_CHECK(hipStreamSynchronize(s));     // the group scratch is released here
-            }
-            if (N > 0) {
-                hipLaunchKernelGGL(ibl_feat_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_sides, d_pairs, pair_idx, pair_d2, d_job_off, J, nn);
-                IBL_LAUNCH_CHECK();
             }
             hipLaunchKernelGGL(ibl_mutual_kernel, dim3(J), dim3(256), 0, s, nn, d_job_off, J, 1, 9, corr, n_corr);
             IBL_LAUNCH_CHECK();
