@@ -298,21 +298,25 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
  *   normals4 [dev] N x float4, fpfh [dev] N x 33 with every row in MATCHING ORDER (bin 11 b + c at position
  *   3 * rank(c) + {b=1: 0, b=2: 1, b=0: 2}, rank over c = 5,4,6,3,7,2,8,1,9,0,10: the three histograms from their centre
  *   bins outwards, interleaved -- the order in which the feature search sums its squared differences, so that its
- *   early-abandon chain reads contiguously), grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
+ *   early-abandon chain reads contiguously), fpfh_split / fpfh_norm [dev]: every row once more as bf16 hi + lo parts
+ *   (x = hi + lo + r, |r| <= 2^-18 |x|) and its squared norm -- the operands of the matrix-core filter of the feature
+ *   search (csrc/reg_featnn.hip), grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
  *   gradients are recomputed per job), bbox [HOST] n_seg x 6 = (min xyz, max xyz) -- all written by
  *   ibl_instance_features_batch (the call synchronises); voxel_size / grad_radius: the parameters they hold for
  *   (grad_radius = 2 * voxel_size * local_dist_factor in register_point_clouds). */
 typedef struct {
     const float* normals4;
     const float* fpfh;
+    const uint16_t* fpfh_split;   /* [dev] N x 96 bf16: terms 0..47 of the hi part | terms 0..47 of the lo part (33 real, 15 zero) */
+    const float* fpfh_norm;       /* [dev] N: |row|^2 */
     const float* grad4;
     const float* bbox;
     double voxel_size;
     double grad_radius;
 } ibl_instance_features;
 int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
-                                int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh, float* grad4,
-                                float* bbox_host, void* stream);
+                                int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh, uint16_t* fpfh_split,
+                                float* fpfh_norm, float* grad4, float* bbox_host, void* stream);
 /* ibl_register_batch with the instance features of the detected pool and / or the memory pool (either may be NULL).
  * reuse_stats_out [HOST][6] or NULL: points served by the instance features, points recomputed, recomputed groups,
  * job sides, distinct (query instance, database instance) feature-matching pairs searched, pair uses by the jobs. */

@@ -58,7 +58,7 @@ _SIGS = {
     "ibl_normals_fpfh_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp]),
     "ibl_register_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,
                                      C.c_double, C.c_uint64, C.c_uint32, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
-    "ibl_instance_features_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp]),
+    "ibl_instance_features_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp]),
     "ibl_register_batch_cached": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,
                                             C.c_double, C.c_uint64, C.c_uint32, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp]),

@@ -125,8 +125,30 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
 // ------------------------------------------------------------------------------------------------
 // registration features of a batch of clouds (shared by the instance cache and by ibl_register_batch_cached)
 // ------------------------------------------------------------------------------------------------
+// every FPFH row once more as bf16 hi | lo parts padded to 48 terms, and its squared norm (operands of reg_featnn.hip)
+__global__ __launch_bounds__(256) void ibl_fpfh_split_kernel(const float* __restrict__ fpfh, int n, unsigned short* __restrict__ split,
+                                                             float* __restrict__ norm) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n * 48) return;
+    const int i = (int)(t / 48), k = (int)(t - (int64_t)i * 48);
+    const float v = k < 33 ? fpfh[(int64_t)i * 33 + k] : 0.0f;
+    const __bf16 bh = (__bf16)v;
+    const __bf16 bl = (__bf16)(v - (float)bh);
+    unsigned short h, l;
+    __builtin_memcpy(&h, &bh, 2);
+    __builtin_memcpy(&l, &bl, 2);
+    split[(int64_t)i * 96 + k] = h;
+    split[(int64_t)i * 96 + 48 + k] = l;
+    if (k == 47) {
+        float a = 0.0f;
+        for (int j = 0; j < 33; ++j) { const float x = fpfh[(int64_t)i * 33 + j]; a = __builtin_fmaf(x, x, a); }
+        norm[i] = a;
+    }
+}
+
 int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, double voxel_size,
-                          double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, float4* grad, hipStream_t s) {
+                          double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, unsigned short* fpfh_split, float* fpfh_norm,
+                          float4* grad, hipStream_t s) {
     const int n = seg_off_host[n_seg];
     if (n <= 0) return IBL_OK;
     int st;
@@ -150,6 +172,10 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
         IBL_ARENA(nbr_cnt, int, n + 64);
         st = ibl_launch_fpfh(gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
         if (st) return st;
+        if (fpfh_split && fpfh_norm) {
+            hipLaunchKernelGGL(ibl_fpfh_split_kernel, dim3((unsigned)(((int64_t)n * 48 + 255) / 256)), dim3(256), 0, s, fpfh, n, fpfh_split, fpfh_norm);
+            IBL_LAUNCH_CHECK();
+        }
     }
     if (grad && gq1 > gq0) {
         if (grad_radius <= 0) return ibl_set_error(IBL_ERR_ARG, "colour gradients need a positive radius");
@@ -164,9 +190,9 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
 }
 
 extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
-                                           int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh, float* grad4,
-                                           float* bbox_host, void* stream) {
-    if (!ctx || !pts4 || !seg_off_dev || !normals4 || !fpfh || voxel_size <= 0)
+                                           int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh,
+                                           uint16_t* fpfh_split, float* fpfh_norm, float* grad4, float* bbox_host, void* stream) {
+    if (!ctx || !pts4 || !seg_off_dev || !normals4 || !fpfh || !fpfh_split || !fpfh_norm || voxel_size <= 0)
         return ibl_set_error(IBL_ERR_ARG, "ibl_instance_features_batch: bad argument");
     if (grad4 && grad_radius <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_instance_features_batch: colour gradients need grad_radius > 0");
     int st = check_seg(seg_off_host, n_seg, "ibl_instance_features_batch");
@@ -203,8 +229,8 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
         }
         const int cnt = off_host[ns];
         st = ibl_features_on_batch(ctx, P + o0, off_dev, off_host, ns, voxel_size, grad_radius, 0, grad4 ? cnt : 0,
-                                   reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33,
-                                   grad4 ? reinterpret_cast<float4*>(grad4) + o0 : nullptr, s);
+                                   reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33, fpfh_split + (int64_t)o0 * 96,
+                                   fpfh_norm + o0, grad4 ? reinterpret_cast<float4*>(grad4) + o0 : nullptr, s);
         if (st) return st;
         s0 = s1;
     }

@@ -81,6 +81,20 @@ int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off
 // per-segment axis-aligned bounding boxes [S][6] = (min xyz, max xyz); empty segments read as zeros
 int ibl_launch_bbox(const float4* pts, const int* seg_off_dev, int n_seg, float* bbox_dev, hipStream_t s);
 
+// feature arrays the registration driver reads in place: [0] detected-pool instance features, [1] memory-pool instance
+// features, [2] groups recomputed in the context of their job
+struct FeatSources { const float4* normals[3]; const float* fpfh[3]; const float4* grad[3]; const unsigned short* split[3]; const float* norm[3]; };
+// one (query instance, database instance) nearest-neighbour search; kind = FeatSources index, src = point offset there,
+// out = offset of the query instance's results in the pair output arrays
+struct FeatPair { int qkind, qsrc, qcnt, dkind, dsrc, dcnt, out, pad; };
+
+// reg_featnn.hip: the searches of `pairs` on the matrix cores (bf16 hi/lo split products as a rigorous filter, exact fp32
+// chains for the few candidates that pass it).  need_pos / need_list (or NULL): only the listed queries (see
+// ibl_feat_need_kernel).  *overflow is set when the candidate list did not fit (the caller falls back to the VALU search).
+int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs, int max_q, const FeatSources& src, int* pair_idx,
+                         float* pair_d2, const int* need_pos, const int* need_list, int out0, int64_t out_count, bool* overflow,
+                         hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------

@@ -25,7 +25,8 @@
 // normals (radius 2 voxel, 30 nn) and FPFH (5 voxel, 100 nn) of every cloud of a batch, colour gradients (grad_radius, 30 nn) of
 // the points [gq0, gq1) -- reg_api.hip
 int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, double voxel_size,
-                          double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, float4* grad, hipStream_t s);
+                          double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, unsigned short* fpfh_split, float* fpfh_norm,
+                          float4* grad, hipStream_t s);
 
 #define ICP_BPJ 8        // blocks per job in the ICP / evaluation reductions (each ends in a 29-value fp64 block reduction)
 #define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
@@ -97,7 +98,6 @@ __global__ __launch_bounds__(256) void ibl_job_gather_kernel(const JobDesc* __re
 struct GroupDesc { int pool; int seg[3]; };          // pool 0 = detected, 1 = memory; -1 = unused slot
 struct FeatCopy { int dst, src, count, kind; };      // kind & 3: 0 detected cache, 1 memory cache, 2 recomputed groups
 #define FEATCOPY_GRAD 4                              // also copy the colour gradients (target sides)
-struct FeatSources { const float4* normals[3]; const float* fpfh[3]; const float4* grad[3]; };
 
 __global__ __launch_bounds__(256) void ibl_group_gather_kernel(const GroupDesc* __restrict__ groups, int G, const float4* __restrict__ det,
                                                                const int* __restrict__ det_off, const float4* __restrict__ mem,
@@ -202,7 +202,6 @@ __global__ __launch_bounds__(256) void ibl_feat_assemble_kernel(const FeatCopy* 
 // nearest neighbours are folded from its pairs in concatenation order with a strict '<' -- exactly the first minimum the
 // scan over the concatenated database finds.  Features are read in place (instance caches / recomputed groups).
 #define FT_TILE 32
-struct FeatPair { int qkind, qsrc, qcnt, dkind, dsrc, dcnt, out, pad; };     // kind: FeatSources index; src: point offset there
 struct SidePairs { int qcnt[3]; int dcnt[3]; int pair[3][3]; };              // per job side: slot sizes, pair ids (-1 = none)
 
 // grid (query tiles, pairs)
@@ -1042,7 +1041,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             const ibl_instance_features* feat[2] = {det_features, mem_features};
             for (int pl = 0; pl < 2; ++pl) {
                 if (!feat[pl]) continue;
-                if (!feat[pl]->normals4 || !feat[pl]->fpfh || !feat[pl]->bbox)
+                if (!feat[pl]->normals4 || !feat[pl]->fpfh || !feat[pl]->fpfh_split || !feat[pl]->fpfh_norm || !feat[pl]->bbox)
                     return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_cached: instance features with null arrays");
                 if (fabs(feat[pl]->voxel_size - voxel_size) > 1e-12 * voxel_size)
                     return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_cached: instance features were built for voxel_size %g, not %g",
@@ -1219,25 +1218,29 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                     if (feat[pl]) {
                         src.normals[pl] = reinterpret_cast<const float4*>(feat[pl]->normals4);
                         src.fpfh[pl] = feat[pl]->fpfh;
+                        src.split[pl] = feat[pl]->fpfh_split;
+                        src.norm[pl] = feat[pl]->fpfh_norm;
                         src.grad[pl] = reinterpret_cast<const float4*>(feat[pl]->grad4);
                     }
                 if (Nd > 0) {
-                    GroupDesc* d_groups; int* d_grp_off; float4 *Pd, *normals_d, *grad_d; float* fpfh_d;
+                    GroupDesc* d_groups; int* d_grp_off; float4 *Pd, *normals_d, *grad_d; float *fpfh_d, *norm_d; unsigned short* split_d;
                     IBL_ARENA(d_groups, GroupDesc, G);
                     IBL_ARENA(d_grp_off, int, G + 1);
                     IBL_ARENA(Pd, float4, Nd + 1);
                     IBL_ARENA(normals_d, float4, Nd + 1);
                     IBL_ARENA(grad_d, float4, Nd + 1);
                     IBL_ARENA(fpfh_d, float, (int64_t)Nd * 33 + 64);
+                    IBL_ARENA(split_d, unsigned short, (int64_t)Nd * 96 + 64);
+                    IBL_ARENA(norm_d, float, (int64_t)Nd + 64);
                     IBL_HIP_CHECK(hipMemcpyAsync(d_groups, groups.data(), sizeof(GroupDesc) * G, hipMemcpyHostToDevice, s));
                     IBL_HIP_CHECK(hipMemcpyAsync(d_grp_off, grp_off.data(), sizeof(int) * (G + 1), hipMemcpyHostToDevice, s));
                     hipLaunchKernelGGL(ibl_group_gather_kernel, dim3((Nd + 255) / 256), dim3(256), 0, s, d_groups, G, det, det_off_dev, mem,
                                        mem_off_dev, d_grp_off, Pd);
                     IBL_LAUNCH_CHECK();
                     st = ibl_features_on_batch(ctx, Pd, d_grp_off, grp_off.data(), G, voxel_size, grad_radius, grp_off[G0], Nd, normals_d, fpfh_d,
-                                               grad_d, s);
+                                               split_d, norm_d, grad_d, s);
                     if (st) return st;
-                    src.normals[2] = normals_d; src.fpfh[2] = fpfh_d; src.grad[2] = grad_d;
+                    src.normals[2] = normals_d; src.fpfh[2] = fpfh_d; src.grad[2] = grad_d; src.split[2] = split_d; src.norm[2] = norm_d;
                 }
                 if (!copies.empty()) {
                     FeatCopy* d_copies;
@@ -1254,7 +1257,14 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 if (!pairs.empty() && N > 0) {
                     IBL_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(FeatPair) * pairs.size(), hipMemcpyHostToDevice, s));
                     // (1) every source point's nearest target: source-query pairs, folded per job
-                    for (int p0 = 0; p0 < n_pairs0; p0 += 32768) {
+                    // matrix-core filter + exact recheck (reg_featnn.hip); the VALU search only if its candidate list overflowed
+                    static const bool use_mfma = getenv("IBL_FEAT_VALU") == nullptr;
+                    bool over = !use_mfma;
+                    if (use_mfma) {
+                        st = ibl_feat_search_mfma(ctx, d_pairs, n_pairs0, max_q, src, pair_idx, pair_d2, nullptr, nullptr, 0, pts0, &over, s);
+                        if (st) return st;
+                    }
+                    for (int p0 = 0; over && p0 < n_pairs0; p0 += 32768) {
                         const unsigned np = (unsigned)std::min(32768, n_pairs0 - p0);
                         hipLaunchKernelGGL(ibl_feat_pair_nn_kernel<false>, dim3((max_q + 255) / 256, np), dim3(256), 0, s, d_pairs + p0, src, pair_idx,
                                            pair_d2, (const int*)nullptr, (const int*)nullptr, 0);
@@ -1286,7 +1296,13 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                         IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, need, need_pos, n1 + 1, s));
                         hipLaunchKernelGGL(ibl_feat_need_list_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, need, need_pos, n1, need_list);
                         IBL_LAUNCH_CHECK();
-                        for (int p0 = 0; p0 < n_pairs1; p0 += 32768) {
+                        over = !use_mfma;
+                        if (use_mfma) {
+                            st = ibl_feat_search_mfma(ctx, d_pairs + n_pairs0, n_pairs1, max_q, src, pair_idx, pair_d2, need_pos, need_list, (int)pts0, n1,
+                                                      &over, s);
+                            if (st) return st;
+                        }
+                        for (int p0 = 0; over && p0 < n_pairs1; p0 += 32768) {
                             const unsigned np = (unsigned)std::min(32768, n_pairs1 - p0);
                             hipLaunchKernelGGL(ibl_feat_pair_nn_kernel<true>, dim3((max_q + 255) / 256, np), dim3(256), 0, s, d_pairs + n_pairs0 + p0, src,
                                                pair_idx, pair_d2, need_pos, need_list, (int)pts0);

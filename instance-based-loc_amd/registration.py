@@ -133,7 +133,8 @@ FEAT_ORDER = np.array([b * 11 + c for c in (5, 4, 6, 3, 7, 2, 8, 1, 9, 0, 10) fo
 
 
 class _FeatStruct(C.Structure):
-    _fields_ = [("normals4", C.c_void_p), ("fpfh", C.c_void_p), ("grad4", C.c_void_p), ("bbox", C.c_void_p),
+    _fields_ = [("normals4", C.c_void_p), ("fpfh", C.c_void_p), ("fpfh_split", C.c_void_p), ("fpfh_norm", C.c_void_p),
+                ("grad4", C.c_void_p), ("bbox", C.c_void_p),
                 ("voxel_size", C.c_double), ("grad_radius", C.c_double)]
 
 
@@ -141,12 +142,14 @@ class InstanceFeatures:
     """Registration features of every cloud of a batch, resident on the device (ibl_instance_features): normals,
     FPFH and (for memory instances) colour gradients, plus host bounding boxes."""
 
-    def __init__(self, normals, fpfh, grad, bbox, voxel_size, grad_radius):
+    def __init__(self, normals, fpfh, fpfh_split, fpfh_norm, grad, bbox, voxel_size, grad_radius):
         self.normals, self.fpfh, self.grad, self.bbox = normals, fpfh, grad, bbox
+        self.fpfh_split, self.fpfh_norm = fpfh_split, fpfh_norm
         self.voxel_size, self.grad_radius = float(voxel_size), float(grad_radius)
 
     def as_struct(self):
-        return _FeatStruct(self.normals.data_ptr(), self.fpfh.data_ptr(), self.grad.data_ptr() if self.grad is not None else None,
+        return _FeatStruct(self.normals.data_ptr(), self.fpfh.data_ptr(), self.fpfh_split.data_ptr(), self.fpfh_norm.data_ptr(),
+                           self.grad.data_ptr() if self.grad is not None else None,
                            self.bbox.ctypes.data, self.voxel_size, self.grad_radius)
 
 
@@ -157,13 +160,15 @@ def instance_features_batch(ctx: RegContext, batch: CloudBatch, voxel_size: floa
     n = max(batch.n, 1)
     normals = torch.empty((n, 4), dtype=torch.float32, device=dev)
     fpfh = torch.empty((n, 33), dtype=torch.float32, device=dev)
+    fpfh_split = torch.empty((n, 96), dtype=torch.bfloat16, device=dev)      # hi | lo parts of every row (matrix-core filter operands)
+    fpfh_norm = torch.empty((n,), dtype=torch.float32, device=dev)
     grad = torch.empty((n, 4), dtype=torch.float32, device=dev) if grad_radius > 0 else None
     bbox = np.zeros((max(batch.n_seg, 1), 6), dtype=np.float32)
     st = _lib.lib.ibl_instance_features_batch(ctx.handle, batch.pts4.data_ptr(), batch.seg_off.data_ptr(), batch.seg_off_host.ctypes.data,
                                               batch.n_seg, float(voxel_size), float(grad_radius), normals.data_ptr(), fpfh.data_ptr(),
-                                              grad.data_ptr() if grad is not None else None, bbox.ctypes.data, _stream())
+                                              fpfh_split.data_ptr(), fpfh_norm.data_ptr(), grad.data_ptr() if grad is not None else None, bbox.ctypes.data, _stream())
     _lib.check(st, "ibl_instance_features_batch")
-    return InstanceFeatures(normals, fpfh, grad, bbox, voxel_size, grad_radius)
+    return InstanceFeatures(normals, fpfh, fpfh_split, fpfh_norm, grad, bbox, voxel_size, grad_radius)
 
 
 REG_HAVE_COLORS = 1
