@@ -1258,7 +1258,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                     IBL_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(FeatPair) * pairs.size(), hipMemcpyHostToDevice, s));
                     // (1) every source point's nearest target: source-query pairs, folded per job
                     // matrix-core filter + exact recheck (reg_featnn.hip); the VALU search only if its candidate list overflowed
-                    static const bool use_mfma = getenv("IBL_FEAT_VALU") == nullptr;
+                    const bool use_mfma = getenv("IBL_FEAT_VALU") == nullptr;      // read per call: the tests compare both searches
                     bool over = !use_mfma;
                     if (use_mfma) {
                         st = ibl_feat_search_mfma(ctx, d_pairs, n_pairs0, max_q, src, pair_idx, pair_d2, nullptr, nullptr, 0, pts0, &over, s);

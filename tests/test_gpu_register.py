@@ -193,3 +193,39 @@ def test_instance_features_chunked_equals_single_pass(ctx):
         one = instance_features_batch(ctx, sub, 0.05, grad_radius=0.15)
         assert torch.equal(ft.grad[b:e], one.grad[:sub.n]) and np.array_equal(ft.bbox[lo:hi], one.bbox)
     assert ctx.status() & 1 == 0
+
+
+def test_matrix_core_feature_search_equals_valu_search(ctx):
+    """the MFMA-filtered nearest-feature search (bf16 hi/lo products + exact recheck) against the full VALU scan it replaces
+    (IBL_FEAT_VALU=1): every output of the registration must be bit-identical -- the filter may only drop rows that cannot be
+    the exact minimum.  Includes a degenerate job (a cloud registered onto itself: every distance 0 is an exact tie)."""
+    import os
+    from ibloc_amd.registration import CloudBatch, instance_features_batch, register_batch
+    w = SynthWorld(9, pts_per_object=3000, E=1, D=8, seed=91, spacing=1.4)
+    rng = np.random.default_rng(92)
+    f = w.make_frame(rng, q=3, pts_per_object=3000, anchor=4)
+    ids = f["ids"]
+    det = CloudBatch.from_numpy([c[0] for c in f["clouds"]] + [w.points[0]], [ro.intensity(c[1]) for c in f["clouds"]] + [ro.intensity(w.colors[0])])
+    mem = CloudBatch.from_numpy(w.points, [ro.intensity(c) for c in w.colors])
+    js = [[0, -1, -1], [0, 1, -1], [0, 1, 2], [2, 1, -1], [3, -1, -1], [1, -1, -1]]
+    jt = [[ids[0], -1, -1], [ids[0], ids[1], -1], [ids[0], ids[1], ids[2]], [8, 0, -1], [0, -1, -1], [7, -1, -1]]
+    fd = instance_features_batch(ctx, det, 0.05)
+    fm = instance_features_batch(ctx, mem, 0.05, grad_radius=0.15)
+    # the split operands reproduce the rows: hi + lo within 2^-17 relative, norms exact to fp32 rounding
+    rows = fm.fpfh[:mem.n].double()
+    rec = fm.fpfh_split[:mem.n, :33].double() + fm.fpfh_split[:mem.n, 48:81].double()
+    assert (rec - rows).abs().max().item() <= 2.0 ** -17 * rows.abs().max().item()
+    assert torch.count_nonzero(fm.fpfh_split[:mem.n, 33:48]).item() == 0
+    assert torch.allclose(fm.fpfh_norm[:mem.n].double(), (rows * rows).sum(1), rtol=1e-5)
+    outs = []
+    for valu in (False, True):
+        if valu:
+            os.environ["IBL_FEAT_VALU"] = "1"
+        try:
+            outs.append(register_batch(ctx, det, mem, js, jt, 0.05, 1.5, 1.5, seed=3, job_id_base=40, det_features=fd, mem_features=fm))
+        finally:
+            os.environ.pop("IBL_FEAT_VALU", None)
+    for k in ("T", "rmse", "fitness", "T_ransac", "ransac_stats"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    # the self-registration converges to the identity
+    assert np.allclose(outs[0]["T"][4], np.eye(4), atol=1e-6) and outs[0]["fitness"][4] > 0.999
