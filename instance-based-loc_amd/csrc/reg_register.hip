@@ -966,6 +966,16 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     const bool center = (flags & IBL_REG_CENTER) != 0;
     hipStream_t s = (hipStream_t)stream;
     ArenaMark mark(ctx);
+    const bool timing = getenv("IBL_TIMING") != nullptr;
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t_prev = now();
+    auto phase = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const double t = now();
+        fprintf(stderr, "[reg] %-28s %7.3f ms\n", what, t - t_prev);
+        t_prev = t;
+    };
 
     // ---- host: job table + job cloud offsets ------------------------------------------------------
     std::vector<JobDesc> jobs(J);
@@ -1013,9 +1023,11 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
 
     // grid C (cell = ICP correspondence distance) lives until the end: ICP neighbours (reach 1) and colour gradients
     // (radius 2 * max_dist, reach 2); grid A (cell = normal radius) only serves the normals
+    phase("job assembly");
     BatchGrid gC;
     st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)max_dist_icp, (int64_t)128 << 20, &gC, s);
     if (st) return st;
+    phase("grid C");
     float4* grad = nullptr;
     // host-side plans of the feature stage; they must outlive their H2D copies (synchronised in the RANSAC prologue)
     std::vector<GroupDesc> groups;
@@ -1099,6 +1111,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 IBL_HIP_CHECK(hipMemcpyAsync(near_flag.data(), d_flags, sizeof(int) * near.size(), hipMemcpyDeviceToHost, s));
                 IBL_HIP_CHECK(hipStreamSynchronize(s));
             }
+            phase("near-pair test");
             // ---- plan: which instances of every job side keep their stand-alone features -------------------------
             std::map<std::array<int, 4>, int> gid[2];
             std::vector<std::array<int, 4>> gkeys[2];
@@ -1207,6 +1220,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 reuse_stats_out[4] = (int64_t)pairs.size();
                 reuse_stats_out[5] = uses;
             }
+            phase("host plan");
             IBL_ARENA(d_sides, SidePairs, 2 * J);
             IBL_ARENA(d_pairs, FeatPair, (int64_t)pairs.size() + 1);
             IBL_ARENA(pair_idx, int, pair_pts + 64);
@@ -1252,6 +1266,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                         IBL_LAUNCH_CHECK();
                     }
                 }
+                phase("recomputed groups + assemble");
                 // matching reads the features in place (caches / recomputed groups), once per distinct pair
                 IBL_HIP_CHECK(hipMemcpyAsync(d_sides, sides.data(), sizeof(SidePairs) * sides.size(), hipMemcpyHostToDevice, s));
                 if (!pairs.empty() && N > 0) {
@@ -1319,6 +1334,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 }
                 IBL_HIP_CHECK(hipStreamSynchronize(s));     // the group scratch is released here
             }
+            phase("feature search");
             hipLaunchKernelGGL(ibl_mutual_kernel, dim3(J), dim3(256), 0, s, nn, d_job_off, J, 1, 9, corr, n_corr);
             IBL_LAUNCH_CHECK();
         }
@@ -1406,6 +1422,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             }
         }
     }
+    phase("ransac");
     // ---- ICP ------------------------------------------------------------------------------------------
     {
         double* partial; int* icp_nn; float* icp_d2;
@@ -1428,6 +1445,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             IBL_LAUNCH_CHECK();
         }
     }
+    phase("icp");
     // ---- results ----------------------------------------------------------------------------------------
     std::vector<IcpState> h_is(J);
     IBL_HIP_CHECK(hipMemcpyAsync(h_is.data(), is, sizeof(IcpState) * J, hipMemcpyDeviceToHost, s));

@@ -380,7 +380,7 @@ __global__ void ibl_set_cls_kernel(float* __restrict__ x, const float* __restric
 // qkv bf16 [B*T][3*D] = [q | k | v], each [heads][64].   out bf16 [B*T][D].
 // ------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
+__global__ __launch_bounds__(256, 2) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
                                                             int D, int heads, float scale) {
     constexpr int KEYS = NT * 16;
     constexpr int KROW = 144;               // bytes per K row (64 bf16 + 16 B pad)
@@ -449,6 +449,9 @@ __global__ __launch_bounds__(256) void ibl_attention_kernel(const u16* __restric
                 mx = fmaxf(mx, a[r]);
             }
             sc[t] = a;
+            // keep the K fragments of later tiles from being hoisted up here: unrolled, the 34 ds_read_b128 of a query tile were
+            // all issued first (398 VGPRs -> one block per CU); with two blocks per CU the other block hides this latency
+            asm volatile("" ::: "memory");
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(256) void ibl_attention_kernel(const u16* __restric
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&packed);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);     // O^T tile: rows = d, columns = q
             }
+            asm volatile("" ::: "memory");
         }
         // O^T layout: row = d = 16 dt + 4 g + r, col = q = fr -> a lane owns four consecutive head dimensions of ONE query row
         // (8-byte stores; the untransposed product left it with single bf16 elements of four rows) and that row's softmax
@@ -556,6 +560,13 @@ static int run_attention(const u16* qkv, u16* out, int B, int T, int D, int head
     dim3 grid(B * heads), block(256);
 #define IBL_ATT(NTV)                                                                                      \
     hipLaunchKernelGGL(ibl_attention_kernel<NTV>, grid, block, 0, s, qkv, out, T, D, heads, scale)
+    if (getenv("IBL_DEBUG_OCC")) {
+        int nb = -1;
+        hipFuncAttributes fa{};
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ibl_attention_kernel<17>, 256, 0);
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ibl_attention_kernel<17>));
+        fprintf(stderr, "[occ] attention<17>: %d blocks/CU, %d regs, %zu B static LDS\n", nb, fa.numRegs, fa.sharedSizeBytes);
+    }
     if (nt <= 4) IBL_ATT(4);
     else if (nt <= 9) IBL_ATT(9);
     else if (nt <= 13) IBL_ATT(13);
