@@ -379,8 +379,9 @@ __global__ void ibl_set_cls_kernel(float* __restrict__ x, const float* __restric
 // Attention: one workgroup (4 waves) per (crop, head); head_dim = 64; T <= 16 * NT.
 // qkv bf16 [B*T][3*D] = [q | k | v], each [heads][64].   out bf16 [B*T][D].
 // ------------------------------------------------------------------------------------------------
+#define ATT_THREADS 512
 template <int NT>
-__global__ __launch_bounds__(256, 2) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
+__global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
                                                             int D, int heads, float scale) {
     constexpr int KEYS = NT * 16;
     constexpr int KROW = 144;               // bytes per K row (64 bf16 + 16 B pad)
@@ -397,14 +398,14 @@ __global__ __launch_bounds__(256, 2) void ibl_attention_kernel(const u16* __rest
     const u16* vbase = qbase + 2 * D;
 
     // stage K rows (zero beyond T)
-    for (int c = tid; c < KEYS * 8; c += 256) {
+    for (int c = tid; c < KEYS * 8; c += ATT_THREADS) {
         const int key = c >> 3, c16 = c & 7;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (key < T) val = *reinterpret_cast<const uint4*>(kbase + (int64_t)key * ld + c16 * 8);
         *reinterpret_cast<uint4*>(sK + key * KROW + c16 * 16) = val;
     }
     // stage V transposed: task = (key pair, 8-wide d chunk); writes packed dwords V^T[d][key..key+1]
-    for (int c = tid; c < (KEYS / 2) * 8; c += 256) {
+    for (int c = tid; c < (KEYS / 2) * 8; c += ATT_THREADS) {
         const int kp = c % (KEYS / 2), dch = c / (KEYS / 2);
         const int key = kp * 2;
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void ibl_attention_kernel(const u16* __rest
 
     const int fr = lane & 15, fg = lane >> 4;
     const int nqt = (T + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         // B operand = Q^T: lane (q = fr, g): Q[q0 + fr][32 ks + 8 g .. +7]
         int qrow = qt * 16 + fr;
         if (qrow >= T) qrow = T - 1;
@@ -557,13 +558,13 @@ extern "C" int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* d, int batch) {
 static int run_attention(const u16* qkv, u16* out, int B, int T, int D, int heads, hipStream_t s) {
     const float scale = 0.125f;   // 1/sqrt(64)
     const int nt = (T + 15) / 16;
-    dim3 grid(B * heads), block(256);
+    dim3 grid(B * heads), block(ATT_THREADS);
 #define IBL_ATT(NTV)                                                                                      \
     hipLaunchKernelGGL(ibl_attention_kernel<NTV>, grid, block, 0, s, qkv, out, T, D, heads, scale)
     if (getenv("IBL_DEBUG_OCC")) {
         int nb = -1;
         hipFuncAttributes fa{};
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ibl_attention_kernel<17>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ibl_attention_kernel<17>, ATT_THREADS, 0);
         (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ibl_attention_kernel<17>));
         fprintf(stderr, "[occ] attention<17>: %d blocks/CU, %d regs, %zu B static LDS\n", nb, fa.numRegs, fa.sharedSizeBytes);
     }
