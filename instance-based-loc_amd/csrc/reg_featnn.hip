@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(16))) float fm_f32x16;
 #define FM_DT 32                 // database rows per chunk (one 32 x 32 MFMA tile per wave)
 #define FM_ROWB 112              // LDS bytes per row: 48 bf16 + 16 pad (2-way instead of 4-way bank conflicts on ds_read_b128)
 #define FM_C 4e-5f               // E = FM_C (|q|^2 + |t|^2)
-#define FM_QUEUE 1280            // per-wave candidate queue (a chunk appends at most 16 x 64 = 1024)
+#define FM_QUEUE 256             // per-wave candidate queue, flushed when fewer than 64 slots (one append step) are left
 
 struct FmCand { int pair, qi, t, pad; };
 
@@ -153,10 +153,10 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
                     if (m) {
                         if (hit) queue[wave][qcount + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(qi, c * FM_DT + 8 * g + 4 * kg + r);
                         qcount += __popcll(m);
+                        if (qcount > FM_QUEUE - 64) flush();
                     }
                 }
             }
-            if (qcount > FM_QUEUE - 16 * 64) flush();
         }
         if (more) stash(tiles[(c + 1) & 1]);        // the other buffer: its readers passed the barrier that ended chunk c - 1
         __syncthreads();
