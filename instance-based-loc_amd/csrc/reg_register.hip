@@ -777,8 +777,11 @@ __global__ __launch_bounds__(256) void ibl_icp_nn_kernel(BatchGrid g, const floa
                                                          const IcpState* __restrict__ st, float radius, float r2, int* __restrict__ nn_idx,
                                                          float* __restrict__ nn_d2) {
     const int ns = job_off[J];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ns) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= ns) return;
+    // walk the sources in the cell order of their own grid (the batch grid covers sources and targets): neighbouring lanes
+    // then query neighbouring cells of the target grid (a rigid transform keeps them together) and share cache lines
+    const int i = g.order[p];
     const int j = seg_of(job_off, J, i);
     const IcpState& S = st[j];
     if (S.done) return;
