@@ -743,14 +743,14 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
     auto scan_row = [&](int z, int y) {
         const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
         const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-        // four candidates per step: their loads are issued together (one thread's walk is a chain of dependent latencies --
+        // eight candidates per step: their loads are issued together (one thread's walk is a chain of dependent latencies --
         // the kernel is bound by it, not by throughput); the comparisons keep the sequential order
-        for (int jj = b; jj < e; jj += 4) {
-            float4 p[4];
+        for (int jj = b; jj < e; jj += 8) {
+            float4 p[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = g.sorted_pts[min(jj + u, e - 1)];
+            for (int u = 0; u < 8; ++u) p[u] = g.sorted_pts[min(jj + u, e - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 if (jj + u >= e) break;
                 const float d2 = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
                 if (d2 < bd) { bd = d2; best = g.order[jj + u]; }
