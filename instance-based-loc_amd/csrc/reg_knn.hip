@@ -53,7 +53,42 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
     const int z0 = max(cz - reach, 0), z1 = min(cz + reach, sg.nz - 1);
     const float bscale = (float)KNN_BINS / r2;
 
+    // Candidate rows (runs of the cell-sorted point array, one per (z, y) of the neighbourhood).  A wave's walk is a chain of
+    // dependent latencies (row bounds -> points -> next row), and these kernels are bound by it, so the bounds of all rows
+    // are fetched in one step (lane r holds row r) and the first 64 points of three rows at a time are in flight together.
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    int my_b = 0, my_e = 0;
+    if (nrows <= 64 && lane < nrows) {
+        const int z = z0 + lane / ny, y = y0 + lane % ny;
+        const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
+        my_b = g.cell_start[row + x0];
+        my_e = g.cell_start[row + x1 + 1];
+    }
     auto scan = [&](auto&& f) {
+        if (nrows <= 64) {
+            for (int r0 = 0; r0 < nrows; r0 += 3) {
+                int b[3], e[3];
+                float4 p[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int r = min(r0 + u, nrows - 1);
+                    b[u] = __shfl(my_b, r, 64);
+                    e[u] = r0 + u < nrows ? __shfl(my_e, r, 64) : b[u];
+                    p[u] = b[u] + lane < e[u] ? g.sorted_pts[b[u] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    for (int jb = b[u]; jb < e[u]; jb += 64) {
+                        const int j = jb + lane;
+                        float4 q4 = p[u];
+                        if (jb != b[u]) q4 = j < e[u] ? g.sorted_pts[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float d2 = j < e[u] ? dist2f(q.x, q.y, q.z, q4.x, q4.y, q4.z) : INFINITY;
+                        f(d2 < r2, j, q4, d2);
+                    }
+                }
+            }
+            return;
+        }
         for (int z = z0; z <= z1; ++z)
             for (int y = y0; y <= y1; ++y) {
                 const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
