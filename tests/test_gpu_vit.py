@@ -93,3 +93,15 @@ def test_embed_crops_end_to_end():
     got = enc.embed(crops).cpu().numpy()
     exp = vo.embed_crops(w, cfg, pp.RECIPES["dinov2"], crops)
     assert rel_l2(got, exp) <= 2e-2 and cosine(got, exp) >= 0.9995
+
+
+def test_embed_micro_batches_on_two_streams_equal_one_stream():
+    """VitEncoder.embed(streams=2) runs two micro-batches on their own HIP streams: identical embeddings"""
+    from ibloc_amd import vit as V
+    cfg = V.CONFIGS["tiny_dino"]
+    enc = V.VitEncoder(cfg, V.random_weights(cfg, 5))
+    crops = torch.randint(0, 256, (160, 64, 48, 3), dtype=torch.uint8, device="cuda")
+    a = enc.embed(crops, streams=1)
+    b = enc.embed(crops, streams=2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
