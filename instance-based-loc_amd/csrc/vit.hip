@@ -382,7 +382,7 @@ __global__ void ibl_set_cls_kernel(float* __restrict__ x, const float* __restric
 #define ATT_THREADS 512
 template <int NT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
-                                                            int D, int heads, float scale) {
+                                                            int D, int heads, float scale, int cls_only) {
     constexpr int KEYS = NT * 16;
     constexpr int KROW = 144;               // bytes per K row (64 bf16 + 16 B pad)
     constexpr int VROW = KEYS * 2 + 16;     // bytes per V^T row
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
-    const int nqt = (T + 15) / 16;
+    const int nqt = cls_only ? 1 : (T + 15) / 16;        // cls_only: only token 0 of every crop is a query (last block of the ViT)
     for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         // B operand = Q^T: lane (q = fr, g): Q[q0 + fr][32 ks + 8 g .. +7]
         int qrow = qt * 16 + fr;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
         // (8-byte stores; the untransposed product left it with single bf16 elements of four rows) and that row's softmax
         // sum is already on this lane (it was reduced over the lane groups above).
         const int qg = qt * 16 + fr;
-        if (qg < T) {
+        if (qg < (cls_only ? 1 : T)) {
             const float inv = 1.0f / sum;
             u16* orow = out + (tok0 + qg) * (int64_t)D + h * 64 + 4 * fg;
 #pragma unroll
@@ -555,12 +555,12 @@ extern "C" int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* d, int batch) {
     return bytes + 6 * 256;
 }
 
-static int run_attention(const u16* qkv, u16* out, int B, int T, int D, int heads, hipStream_t s) {
+static int run_attention(const u16* qkv, u16* out, int B, int T, int D, int heads, int cls_only, hipStream_t s) {
     const float scale = 0.125f;   // 1/sqrt(64)
     const int nt = (T + 15) / 16;
     dim3 grid(B * heads), block(ATT_THREADS);
 #define IBL_ATT(NTV)                                                                                      \
-    hipLaunchKernelGGL(ibl_attention_kernel<NTV>, grid, block, 0, s, qkv, out, T, D, heads, scale)
+    hipLaunchKernelGGL(ibl_attention_kernel<NTV>, grid, block, 0, s, qkv, out, T, D, heads, scale, cls_only)
     if (getenv("IBL_DEBUG_OCC")) {
         int nb = -1;
         hipFuncAttributes fa{};
@@ -630,40 +630,61 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
     }
     for (int l = 0; l < d->n_blocks_run; ++l) {
         const ibl_vit_layer* L = &w->layers[l];
+        // Only the CLS row leaves the encoder (unless all tokens are asked for), so in the LAST block the other rows are dead
+        // after they have served as keys / values: its query projection, attention, output projection and MLP run on the CLS
+        // rows alone (M = batch instead of batch * T; every row of a GEMM is computed independently, so the CLS rows come out
+        // bit-identical).  The kernels take row strides, the CLS rows are addressed in place (stride T * D).
+        const bool cls_only = (l == d->n_blocks_run - 1) && !(d->flags & IBL_VIT_OUT_ALL_TOKENS);
+        const int64_t TD = (int64_t)T * D;
         hipLaunchKernelGGL(ibl_layernorm_kernel<false>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, L->ln1_g,
                            L->ln1_b, d->ln_eps, (void*)xn, (int64_t)D);
         IBL_LAUNCH_CHECK();
-        {
+        if (!cls_only) {
             GemmEpi e{};
             e.bias = L->b_qkv; e.out = qkv; e.ldo = 3 * D;
             st = launch_gemm<EPI_BIAS_BF16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv), D, (int)Rn, 3 * D, D, e, s);
             if (st) return st;
+        } else {
+            GemmEpi e{};                                  // keys and values of every token: weight rows D .. 3D
+            e.bias = L->b_qkv + D; e.out = qkv + D; e.ldo = 3 * D;
+            st = launch_gemm<EPI_BIAS_BF16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv) + (int64_t)D * D, D, (int)Rn, 2 * D, D, e, s);
+            if (st) return st;
+            GemmEpi q{};                                  // queries of the CLS rows only
+            q.bias = L->b_qkv; q.out = qkv; q.ldo = 3 * TD;
+            st = launch_gemm<EPI_BIAS_BF16>(xn, TD, reinterpret_cast<const u16*>(L->w_qkv), D, batch, D, D, q, s);
+            if (st) return st;
         }
-        st = run_attention(qkv, att, batch, T, D, H, s);
+        st = run_attention(qkv, att, batch, T, D, H, cls_only ? 1 : 0, s);
         if (st) return st;
         {
             GemmEpi e{};
-            e.bias = L->b_o; e.scale = L->ls1; e.out = x; e.ldo = D;
-            st = launch_gemm<EPI_RESID_F32>(att, D, reinterpret_cast<const u16*>(L->w_o), D, (int)Rn, D, D, e, s);
+            e.bias = L->b_o; e.scale = L->ls1; e.out = x; e.ldo = cls_only ? TD : D;
+            st = launch_gemm<EPI_RESID_F32>(att, cls_only ? TD : D, reinterpret_cast<const u16*>(L->w_o), D, cls_only ? batch : (int)Rn, D, D,
+                                            e, s);
             if (st) return st;
         }
-        hipLaunchKernelGGL(ibl_layernorm_kernel<false>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, L->ln2_g,
-                           L->ln2_b, d->ln_eps, (void*)xn, (int64_t)D);
+        if (!cls_only) {
+            hipLaunchKernelGGL(ibl_layernorm_kernel<false>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, L->ln2_g,
+                               L->ln2_b, d->ln_eps, (void*)xn, (int64_t)D);
+        } else {
+            hipLaunchKernelGGL(ibl_layernorm_kernel<false>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, x, TD, (int64_t)batch, D,
+                               L->ln2_g, L->ln2_b, d->ln_eps, (void*)fin_bf, (int64_t)D);
+        }
         IBL_LAUNCH_CHECK();
+        const u16* mlp_in = cls_only ? fin_bf : xn;
+        const int mlp_rows = cls_only ? batch : (int)Rn;
         {
             GemmEpi e{};
             e.bias = L->b_fc1; e.out = hid; e.ldo = d->mlp_dim;
             if (d->flags & IBL_VIT_QUICK_GELU)
                 return ibl_set_error(IBL_ERR_UNSUPPORTED, "ibl_vit_forward: QuickGELU not built");
-            st = launch_gemm<EPI_BIAS_GELU_BF16>(xn, D, reinterpret_cast<const u16*>(L->w_fc1), D, (int)Rn, d->mlp_dim, D,
-                                                 e, s);
+            st = launch_gemm<EPI_BIAS_GELU_BF16>(mlp_in, D, reinterpret_cast<const u16*>(L->w_fc1), D, mlp_rows, d->mlp_dim, D, e, s);
             if (st) return st;
         }
         {
             GemmEpi e{};
-            e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = D;
-            st = launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, (int)Rn,
-                                            D, d->mlp_dim, e, s);
+            e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = cls_only ? TD : D;
+            st = launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
             if (st) return st;
         }
     }
