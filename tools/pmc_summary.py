@@ -38,7 +38,7 @@ def per_kernel(rows, last_n_of=None):
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
-    gemm_launches = int(sys.argv[4]) if len(sys.argv) > 4 else 49     # 12 layers x 4 + patch embedding, one 224-crop batch
+    gemm_launches = int(sys.argv[4]) if len(sys.argv) > 4 else 50     # 11 layers x 4 + the CLS-only last layer x 5 + patch embedding, one 224-crop batch
     out = {}
     for tag, rows, scale in (("fetch", fetch, 1024.0 * 2.0), ("write", write, 1024.0)):
         g = [(i, k, v) for i, k, v, _ in rows if "ibl_gemm_bf16_tn" in k]
