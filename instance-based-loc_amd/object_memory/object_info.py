@@ -43,3 +43,90 @@ class ObjectInfo:
         self.pointcloud = Cloud(pts, cols)
         self._process_pointcloud()
         return self
+
+    # ---- persistence: the reference's per-object directory layout (object_info.py:109-118) --------------------------
+    def save(self, save_directory: str):
+        """`pointcloud.ply` (binary little-endian, double x/y/z + uchar red/green/blue -- what Open3D's write_point_cloud
+        emits for a coloured cloud) and `info.pkl` with names / embeddings / max_embeddings_num."""
+        import os
+        import pickle
+        os.makedirs(save_directory, exist_ok=True)
+        write_ply(os.path.join(save_directory, "pointcloud.ply"), self.pointcloud.points, self.pointcloud.colors)
+        with open(os.path.join(save_directory, "info.pkl"), "wb") as f:
+            pickle.dump({"names": self.names, "embeddings": self.embeddings, "max_embeddings_num": self.max_embeddings_num}, f)
+
+    @classmethod
+    def load(cls, load_directory: str, id: int = 0):
+        import os
+        import pickle
+        pts, cols = read_ply(os.path.join(load_directory, "pointcloud.ply"))
+        with open(os.path.join(load_directory, "info.pkl"), "rb") as f:
+            info = pickle.load(f)
+        obj = cls(id, info["names"][0], info["embeddings"][0], Cloud(pts, cols), info.get("max_embeddings_num", 1000000))
+        obj.names = list(info["names"])
+        obj.embeddings = [np.asarray(e) for e in info["embeddings"]]
+        obj._compute_means()
+        return obj
+
+
+_PLY_TYPES = {"char": "i1", "uchar": "u1", "int8": "i1", "uint8": "u1", "short": "i2", "ushort": "u2", "int16": "i2", "uint16": "u2",
+              "int": "i4", "uint": "u4", "int32": "i4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def write_ply(path, points, colors=None):
+    """Vertex-only PLY, binary little-endian: double x, y, z (+ uchar red, green, blue from colours in [0, 1])."""
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    fields = [("x", "<f8"), ("y", "<f8"), ("z", "<f8")]
+    if colors is not None and len(colors) == len(pts):
+        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    rec = np.zeros(len(pts), dtype=fields)
+    rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    if len(fields) == 6:
+        c8 = np.rint(np.clip(np.asarray(colors, dtype=np.float64), 0.0, 1.0) * 255.0).astype(np.uint8)
+        rec["red"], rec["green"], rec["blue"] = c8[:, 0], c8[:, 1], c8[:, 2]
+    names = {"<f8": "double", "u1": "uchar"}
+    header = ["ply", "format binary_little_endian 1.0", "comment written by ibloc_amd", f"element vertex {len(pts)}"]
+    header += [f"property {names[t]} {n}" for n, t in fields] + ["end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(header) + "\n").encode("ascii"))
+        f.write(rec.tobytes())
+
+
+def read_ply(path):
+    """-> (points (N, 3) float64, colors (N, 3) float64 in [0, 1] or None).  Vertex element only; binary little-endian or ascii."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, n, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated PLY header")
+            tok = line.decode("ascii").split()
+            if not tok or tok[0] == "comment":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise ValueError(f"{path}: list properties on vertices are not supported")
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        if fmt == "binary_little_endian":
+            rec = np.frombuffer(f.read(n * np.dtype([(p, "<" + t) for p, t in props]).itemsize), dtype=[(p, "<" + t) for p, t in props])
+        elif fmt == "ascii":
+            rows = np.loadtxt(f, max_rows=n, ndmin=2) if n else np.zeros((0, len(props)))
+            rec = {p: rows[:, i] for i, (p, _) in enumerate(props)}
+        else:
+            raise ValueError(f"{path}: unsupported PLY format {fmt}")
+    pts = np.stack([np.asarray(rec[k], dtype=np.float64) for k in ("x", "y", "z")], axis=1) if n else np.zeros((0, 3))
+    cols = None
+    if all(k in dict(props) for k in ("red", "green", "blue")):
+        scale = 255.0 if dict(props)["red"] == "u1" else 1.0
+        cols = np.stack([np.asarray(rec[k], dtype=np.float64) for k in ("red", "green", "blue")], axis=1) / scale if n else np.zeros((0, 3))
+    return pts, cols

@@ -111,6 +111,26 @@ class ObjectMemory():
         with open(save_directory, "wb") as f:
             pickle.dump((mem, floors), f)
 
+    def save(self, save_directory: str):
+        """object_memory.py:753-777: `objects/<id>/{pointcloud.ply, info.pkl}`, `floors/all_floors/`, `memory.txt` (the combined
+        PLY dumps of the reference are visualisation aids and are not written)."""
+        os.makedirs(os.path.join(save_directory, "objects"), exist_ok=True)
+        with open(os.path.join(save_directory, "memory.txt"), "w") as f:
+            f.write(self.__repr__())
+        for obj in self.memory:
+            obj.save(os.path.join(save_directory, "objects", f"{obj.id}"))
+        if self.floors is not None:
+            self.floors.save(os.path.join(save_directory, "floors", "all_floors"))
+
+    def load_directory(self, load_directory: str):
+        """the directory layout written by `save` of either implementation"""
+        root = os.path.join(load_directory, "objects")
+        ids = sorted((d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d))), key=lambda d: (not d.isdigit(), int(d) if d.isdigit() else 0, d))
+        self.memory = [ObjectInfo.load(os.path.join(root, d), id=i) for i, d in enumerate(ids)]
+        floors = os.path.join(load_directory, "floors", "all_floors")
+        self.floors = ObjectInfo.load(floors) if os.path.isdir(floors) else None
+        self._engine = None
+
     def load(self, load_directory: str):
         """object_memory.py:831-846.  A pickle written by the reference resolves `object_memory.object_info.ObjectInfo` to this
         package's class when it is first on sys.path; its attributes are taken as they are."""
