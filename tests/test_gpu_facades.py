@@ -136,3 +136,10 @@ def test_object_memory_pickle_round_trip(tmp_path):
     ra = a.localise_detections(f["det_emb"], f["clouds"], fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
     rb = b.localise_detections(f["det_emb"], f["clouds"], fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
     assert ra.assignments == rb.assignments and np.array_equal(ra.pose, rb.pose)
+    # the per-object directory layout (objects/<id>/pointcloud.ply + info.pkl): colours go through 8 bits, points are exact
+    a.save(str(tmp_path / "dir"))
+    c = ObjectMemory("cuda", None, None, 300.0, 300.0, get_embeddings_func=dummy)
+    c.load_directory(str(tmp_path / "dir"))
+    assert len(c.memory) == w.M and np.array_equal(c.memory[3].pointcloud.points, a.memory[3].pointcloud.points)
+    rc = c.localise_detections(f["det_emb"], f["clouds"], fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
+    assert rc.assignments == ra.assignments and np.isfinite(rc.pose).all()      # (8-bit colours may pick another best candidate)
