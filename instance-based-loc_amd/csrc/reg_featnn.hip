@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "reg_common.h"
 
@@ -204,7 +205,8 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
     if (n_pairs <= 0 || out_count <= 0) return IBL_OK;
     if (n_pairs > 32768) { *overflow = true; return IBL_OK; }      // candidates carry the pair id as blockIdx.y: one launch only
     ArenaMark mark(ctx);
-    const int cand_cap = (int)std::min<int64_t>(out_count * 8 + 65536, (int64_t)1 << 27);
+    int cand_cap = (int)std::min<int64_t>(out_count * 8 + 65536, (int64_t)1 << 27);
+    if (const char* e = getenv("IBL_FEAT_CAND_CAP")) cand_cap = std::max(1, atoi(e));      // tests: force the overflow fallback
     float* up; FmCand* cand; int* n_cand; unsigned long long* best;
     IBL_ARENA(up, float, out_count + 64);
     IBL_ARENA(cand, FmCand, cand_cap);

@@ -218,14 +218,14 @@ def test_matrix_core_feature_search_equals_valu_search(ctx):
     assert torch.count_nonzero(fm.fpfh_split[:mem.n, 33:48]).item() == 0
     assert torch.allclose(fm.fpfh_norm[:mem.n].double(), (rows * rows).sum(1), rtol=1e-5)
     outs = []
-    for valu in (False, True):
-        if valu:
-            os.environ["IBL_FEAT_VALU"] = "1"
+    for env in ({}, {"IBL_FEAT_VALU": "1"}, {"IBL_FEAT_CAND_CAP": "100"}):        # matrix cores | VALU scan | overflow -> fallback
+        os.environ.update(env)
         try:
             outs.append(register_batch(ctx, det, mem, js, jt, 0.05, 1.5, 1.5, seed=3, job_id_base=40, det_features=fd, mem_features=fm))
         finally:
-            os.environ.pop("IBL_FEAT_VALU", None)
+            for k in env:
+                os.environ.pop(k, None)
     for k in ("T", "rmse", "fitness", "T_ransac", "ransac_stats"):
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]), k
     # the self-registration converges to the identity
     assert np.allclose(outs[0]["T"][4], np.eye(4), atol=1e-6) and outs[0]["fitness"][4] > 0.999
