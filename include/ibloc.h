@@ -299,7 +299,7 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
  *   3 * rank(c) + {b=1: 0, b=2: 1, b=0: 2}, rank over c = 5,4,6,3,7,2,8,1,9,0,10: the three histograms from their centre
  *   bins outwards, interleaved -- the order in which the feature search sums its squared differences, so that its
  *   early-abandon chain reads contiguously), fpfh_split / fpfh_norm [dev]: every row once more as bf16 hi + lo parts
- *   (x = hi + lo + r, |r| <= 2^-18 |x|) and its squared norm -- the operands of the matrix-core filter of the feature
+ *   (x = hi + lo + r, |r| <= 2^-16 |x|) and its squared norm -- the operands of the matrix-core filter of the feature
  *   search (csrc/reg_featnn.hip), grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
  *   gradients are recomputed per job), bbox [HOST] n_seg x 6 = (min xyz, max xyz) -- all written by
  *   ibl_instance_features_batch (the call synchronises); voxel_size / grad_radius: the parameters they hold for

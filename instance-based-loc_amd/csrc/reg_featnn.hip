@@ -5,10 +5,16 @@
 // removal, their nearest features are far (d2 ~ 1000) and the early-abandon VALU search of reg_register.hip runs nearly the
 // whole 33-term chain for every candidate: 80 VALU instructions per (wave, candidate), 8.6 ms per step.  Here the matrix
 // cores do the bulk and the exact arithmetic is kept for the few candidates that can matter:
-//   d2(q, t) = |q|^2 + |t|^2 - 2 q.t,   q.t ~ qh.th + qh.tl + ql.th   (x = xh + xl + r, bf16 hi/lo split, |r| <= 2^-18 |x|)
-// computed with v_mfma_f32_32x32x16_bf16 (three products x three 16-wide k steps over the 33 -> 48 padded terms).  With
-// E = 4e-5 (|q|^2 + |t|^2) >= |approx - exact fp32 chain| (dropped split terms 1.2e-5 |q||t| * 2, fp32 accumulation of 144
-// exact bf16 products 1.7e-5 |q||t|, norms and the chain's own rounding 6e-6 (|q|^2 + |t|^2), and |q||t| <= (|q|^2+|t|^2)/2):
+//   d2(q, t) = |q|^2 + |t|^2 - 2 q.t,   q.t ~ qh.th + qh.tl + ql.th   (x = xh + xl + r, bf16 hi/lo split, |r| <= 2^-16 |x|)
+// computed with v_mfma_f32_32x32x16_bf16 (three products x three 16-wide k steps over the 33 -> 48 padded terms).  Error of
+// approx against the fp32 chain the VALU search / oracle evaluates, with N = |q|^2 + |t|^2 (so |q||t| <= N / 2, d2 <= 2 N):
+//   split      bf16 keeps 8 significant bits: |x - xh| <= 2^-8 |x|, |x - xh - xl| <= 2^-16 |x|; the dropped terms ql.tl, rq.t,
+//              q.rt are each <= 2^-16 |q||t|, times the factor 2 of the expansion:          6 * 2^-16 |q||t| <= 4.6e-5 N
+//   accumulate 144 exact bf16 products summed in fp32 by the MFMAs, times 2:                 1.8e-5 |q||t|    <= 0.9e-5 N
+//   norms      two 33-term fp32 fmaf chains:                                                                     0.2e-5 N
+//   chain      the exact chain's own rounding (34 roundings of values <= d2):                                    0.4e-5 N
+//   epilogue   the three fp32 operations that form the bound:                                                    0.1e-5 N
+// total <= 6.2e-5 N; E = FM_C N with FM_C = 7e-5.
 //   pass 1   up(q) = min_t (approx + E)                       -- an upper bound of the exact minimum
 //   pass 2   every t with approx - E <= up(q) is a candidate  -- the exact minimiser (and every exact tie) is among them
 //   exact    the fp32 fmaf chain of the VALU search for each candidate, folded with a 64-bit atomic min on
@@ -26,7 +32,7 @@ typedef __attribute__((ext_vector_type(16))) float fm_f32x16;
 
 #define FM_DT 32                 // database rows per chunk (one 32 x 32 MFMA tile per wave)
 #define FM_ROWB 112              // LDS bytes per row: 48 bf16 + 16 pad (2-way instead of 4-way bank conflicts on ds_read_b128)
-#define FM_C 4e-5f               // E = FM_C (|q|^2 + |t|^2)
+#define FM_C 7e-5f               // E = FM_C (|q|^2 + |t|^2)
 #define FM_QUEUE 256             // per-wave candidate queue, flushed when fewer than 64 slots (one append step) are left
 
 struct FmCand { int pair, qi, t, pad; };
