@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(16))) float fm_f32x16;
 #define FM_DT 32                 // database rows per chunk (one 32 x 32 MFMA tile per wave)
 #define FM_ROWB 112              // LDS bytes per row: 48 bf16 + 16 pad (2-way instead of 4-way bank conflicts on ds_read_b128)
 #define FM_C 7e-5f               // E = FM_C (|q|^2 + |t|^2)
+#define FM_NQ 2                  // 32-query tiles per wave (they share every database fragment read)
 #define FM_QUEUE 256             // per-wave candidate queue, flushed when fewer than 64 slots (one append step) are left
 
 struct FmCand { int pair, qi, t, pad; };
@@ -43,7 +44,7 @@ struct FmTile {
     __attribute__((aligned(16))) float dn[FM_DT];        // (1 +- C) |t|^2 for pass 1 / 2   (+inf past the end of the database)
 };
 
-// grid (query tiles of 128, pairs); PASS 1: up[] ; PASS 2: candidates.  Operands come pre-split from the instance features
+// grid (query tiles of 128 FM_NQ, pairs); PASS 1: up[] ; PASS 2: candidates.  Operands come pre-split from the instance features
 // (fpfh_split: 48 hi | 48 lo bf16 per row, fpfh_norm).  Database chunks of 32 rows are copied to LDS (16-byte pieces, fetched
 // into registers one chunk ahead); every wave holds its 32 queries as the B operand in registers.
 template <int PASS, bool INDEXED>
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
     const FeatPair P = pairs[blockIdx.y];
     int n_q = P.qcnt, l0 = 0;
     if (INDEXED) { l0 = need_pos[P.out - out0]; n_q = need_pos[P.out - out0 + P.qcnt] - l0; }
-    const int q0 = blockIdx.x * 128;
+    const int q0 = blockIdx.x * (128 * FM_NQ);
     if (q0 >= n_q) return;
     __shared__ FmTile tiles[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,20 +64,27 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
     const float* __restrict__ dnorm = src.norm[P.dkind] + P.dsrc;
     constexpr float SGN = PASS == 1 ? 1.0f + FM_C : 1.0f - FM_C;
 
-    // this wave's 32 queries as the B operand: lane (n, kg) holds terms 16 s + 8 kg + 0..7 of query n for k step s
-    const int qv = q0 + wave * 32 + n;
-    const bool valid = qv < n_q;
-    const int qc = valid ? qv : n_q - 1;
-    const int qi = INDEXED ? need_list[l0 + qc] - (P.out - out0) : qc;        // local index inside the query instance
-    fm_bf16x8 qh[3], ql[3];
+    // this wave's FM_NQ x 32 queries as B operands (one set of database fragments serves them all): lane (n, kg) holds terms
+    // 16 s + 8 kg + 0..7 of query n for k step s
+    bool valid[FM_NQ];
+    int qi[FM_NQ];                                     // local index inside the query instance
+    fm_bf16x8 qh[FM_NQ][3], ql[FM_NQ][3];
+    float qn_s[FM_NQ], mup[FM_NQ];
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-        const uint4 h = qs[(int64_t)qi * 12 + 2 * s3 + kg], l = qs[(int64_t)qi * 12 + 6 + 2 * s3 + kg];
-        __builtin_memcpy(&qh[s3], &h, 16);
-        __builtin_memcpy(&ql[s3], &l, 16);
+    for (int u = 0; u < FM_NQ; ++u) {
+        const int qv = q0 + (wave * FM_NQ + u) * 32 + n;
+        valid[u] = qv < n_q;
+        const int qc = valid[u] ? qv : n_q - 1;
+        qi[u] = INDEXED ? need_list[l0 + qc] - (P.out - out0) : qc;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const uint4 h = qs[(int64_t)qi[u] * 12 + 2 * s3 + kg], l = qs[(int64_t)qi[u] * 12 + 6 + 2 * s3 + kg];
+            __builtin_memcpy(&qh[u][s3], &h, 16);
+            __builtin_memcpy(&ql[u][s3], &l, 16);
+        }
+        qn_s[u] = src.norm[P.qkind][P.qsrc + qi[u]] * SGN;
+        mup[u] = PASS == 1 ? INFINITY : up[P.out + qi[u]];
     }
-    const float qn_s = src.norm[P.qkind][P.qsrc + qi] * SGN;
-    float mup = PASS == 1 ? INFINITY : up[P.out + qi];
 
     // chunk staging: 32 rows x 12 pieces = 384 pieces of 16 bytes; thread t carries pieces t and t + 256 (t < 128)
     const int n_chunks = (P.dcnt + FM_DT - 1) / FM_DT;
@@ -121,44 +129,48 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
         FmTile& T = tiles[c & 1];
         const bool more = c + 1 < n_chunks;
         if (more) fetch((c + 1) * FM_DT);
-        fm_f32x16 acc;
+        fm_f32x16 acc[FM_NQ];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int u = 0; u < FM_NQ; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][i] = 0.0f;
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
             // A operand: lane (m = n, kg) holds terms 16 s + 8 kg + 0..7 of database row m
             const fm_bf16x8 ah = *reinterpret_cast<const fm_bf16x8*>(T.hi + n * FM_ROWB + 32 * s3 + 16 * kg);
             const fm_bf16x8 al = *reinterpret_cast<const fm_bf16x8*>(T.lo + n * FM_ROWB + 32 * s3 + 16 * kg);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[s3], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < FM_NQ; ++u) {
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[u][s3], acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[u][s3], acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[u][s3], acc[u], 0, 0, 0);
+            }
         }
-        // acc[i] = q . t for database row m = 8 (i / 4) + 4 kg + (i % 4) of the chunk and query n;
+        // acc[u][i] = q . t for database row m = 8 (i / 4) + 4 kg + (i % 4) of the chunk and query n of tile u;
         // bound(i) = (1 +- C)(|q|^2 + |t|^2) - 2 q . t
-        float lowest = INFINITY;
+        float dnv[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 du = *reinterpret_cast<const float4*>(&T.dn[8 * g + 4 * kg]);
-            const float d4[4] = {du.x, du.y, du.z, du.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lowest = fminf(lowest, __builtin_fmaf(-2.0f, acc[4 * g + r], d4[r] + qn_s));
+            dnv[4 * g] = du.x; dnv[4 * g + 1] = du.y; dnv[4 * g + 2] = du.z; dnv[4 * g + 3] = du.w;
         }
-        if (PASS == 1) {
-            mup = fminf(mup, lowest);
-        } else if (__ballot(lowest <= mup && valid) != 0ull) {
-            // some query of this wave has a candidate in this chunk: append to the wave's LDS queue (ballot compaction, no
-            // atomics); the queue goes to the global list in batches -- one atomic per ~200 candidates instead of one each
-            // (two million same-address atomics per step took longer than the whole search)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 du = *reinterpret_cast<const float4*>(&T.dn[8 * g + 4 * kg]);
-                const float d4[4] = {du.x, du.y, du.z, du.w};
+        for (int u = 0; u < FM_NQ; ++u) {
+            float lowest = INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool hit = valid && __builtin_fmaf(-2.0f, acc[4 * g + r], d4[r] + qn_s) <= mup;
+            for (int i = 0; i < 16; ++i) lowest = fminf(lowest, __builtin_fmaf(-2.0f, acc[u][i], dnv[i] + qn_s[u]));
+            if (PASS == 1) {
+                mup[u] = fminf(mup[u], lowest);
+            } else if (__ballot(lowest <= mup[u] && valid[u]) != 0ull) {
+                // some query of this tile has a candidate in this chunk: append to the wave's LDS queue (ballot compaction, no
+                // atomics); the queue goes to the global list in batches -- one atomic per ~200 candidates instead of one each
+                // (two million same-address atomics per step took longer than the whole search)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool hit = valid[u] && __builtin_fmaf(-2.0f, acc[u][i], dnv[i] + qn_s[u]) <= mup[u];
                     const unsigned long long m = __ballot(hit);
                     if (m) {
-                        if (hit) queue[wave][qcount + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(qi, c * FM_DT + 8 * g + 4 * kg + r);
+                        if (hit) queue[wave][qcount + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(qi[u], c * FM_DT + 8 * (i >> 2) + 4 * kg + (i & 3));
                         qcount += __popcll(m);
                         if (qcount > FM_QUEUE - 64) flush();
                     }
@@ -169,8 +181,11 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
         __syncthreads();
     }
     if (PASS == 1) {
-        mup = fminf(mup, __shfl_xor(mup, 32, 64));
-        if (valid && kg == 0) up[P.out + qi] = mup;
+#pragma unroll
+        for (int u = 0; u < FM_NQ; ++u) {
+            const float m2 = fminf(mup[u], __shfl_xor(mup[u], 32, 64));
+            if (valid[u] && kg == 0) up[P.out + qi[u]] = m2;
+        }
     } else {
         flush();
     }
@@ -225,7 +240,7 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
     const bool indexed = need_pos != nullptr;
     for (int p0 = 0; p0 < n_pairs; p0 += 32768) {
         const unsigned np = (unsigned)std::min(32768, n_pairs - p0);
-        const dim3 grid((max_q + 127) / 128, np);
+        const dim3 grid((max_q + 128 * FM_NQ - 1) / (128 * FM_NQ), np);
         if (indexed) {
             hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, true>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0);
             IBL_LAUNCH_CHECK();
