@@ -107,6 +107,12 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    // fp32 read-modify-write epilogue: MFMA row 4 fg + r of n-tile j is weight row 16 j + 4 fg + r (natural order), so that one
+    // wave instruction covers 64 contiguous bytes of each of its 16 output rows; with the 16-consecutive-columns-per-lane map
+    // of the bf16 epilogues every float4 instruction touched 64 separate cache lines and the address coalescer (not HBM) bound
+    // the epilogue: 52 k clocks per tile, more than the projection's K loop.
+    constexpr bool NAT = EPI == EPI_RESID_F32;
+#define KEYW(r) (NAT ? key_act(r) : key_w(r))
     // XCD-aware remap: consecutive tiles along N (sharing the A panel) stay on one XCD's L2
     const int nbn = N / BN;
     const int nbm = (M + BM - 1) / BM;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
 #pragma unroll
     for (int i = 0; i < GW; ++i) {
         const int r = (wave + NW * i) * 8 + (lane >> 3), pch = lane & 7;
-        w_src[i] = W + (int64_t)(col0 + r) * ldw + ((pch ^ key_w(r)) << 3);
+        w_src[i] = W + (int64_t)(col0 + r) * ldw + ((pch ^ KEYW(r)) << 3);
     }
 #define GEMM_GLDS(buf, kt)                                                                                              \
     do {                                                                                                                \
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
 #pragma unroll
     for (int i = 0; i < MI; ++i) arow[i] = wm * (MI * 16) + i * 16 + fr;              // activation row (B operand column)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wrow[j] = wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);  // weight row of MFMA row fr in n-tile j
+    for (int j = 0; j < 4; ++j) wrow[j] = NAT ? wn * 64 + 16 * j + fr : wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);  // weight row of MFMA row fr in n-tile j
     // One K step = 2 * MI groups of 4 MFMAs.  The GA + GW direct-to-LDS pieces of the NEXT tile are issued one at a time
     // between those groups: a piece blocks its wave's issue port for ~100 cycles, and eight of them back to back at the top
     // of the step (right after the barrier, in every wave at once) left the MFMA pipe idle for a third of the step.
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
             const int ch = 4 * ks + fg;
             bf16x8 af[MI], wf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + wrow[j] * LDS_ROW + ((ch ^ key_w(wrow[j])) << 4));
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + wrow[j] * LDS_ROW + ((ch ^ KEYW(wrow[j])) << 4));
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ key_act(arow[i])) << 4));
 #pragma unroll
@@ -207,6 +213,36 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
     GEMM_STAMP(2);
 
     // epilogue.  D layout: col = lane & 15 -> output row m; MFMA row 4*fg + r of n-tile j -> output column 16*fg + 4*j + r
+    if (NAT) {
+        // x[row][n] += scale[n] * (acc + bias[n]); lane (fr, fg) owns columns 16 j + 4 fg + 0..3 of n-tile j
+        const int nb = col0 + wn * 64 + 4 * fg;
+        float4 b4[4], s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b4[j] = epi.bias ? *reinterpret_cast<const float4*>(epi.bias + nb + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s4[j] = epi.scale ? *reinterpret_cast<const float4*>(epi.scale + nb + 16 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = row0 + wm * (MI * 16) + i * 16 + fr;
+            if (row >= M) continue;
+            float* orow = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + nb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4* o = reinterpret_cast<float4*>(orow + 16 * j);
+                float4 x = *o;
+                x.x += (acc[i][j][0] + b4[j].x) * s4[j].x; x.y += (acc[i][j][1] + b4[j].y) * s4[j].y;
+                x.z += (acc[i][j][2] + b4[j].z) * s4[j].z; x.w += (acc[i][j][3] + b4[j].w) * s4[j].w;
+                *o = x;
+            }
+        }
+#ifdef IBL_GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GEMM_STAMP(3);
+#endif
+        return;
+    }
     const int n0 = col0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
     float bias[16], scale[16];
 #pragma unroll
