@@ -56,6 +56,7 @@ constexpr int LDS_ROW = GBK * 2;        // 128-byte tile rows, XOR-swizzled 16-b
 //   weight tile:     key = ((r >> 4) & 3) * 2 + ((r >> 1) & 1)   (fragment rows are 16a + 4j + b, see below)
 __device__ __forceinline__ int key_act(int r) { return r & 7; }
 __device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
+__device__ __forceinline__ int key_pair(int r) { return (((r >> 3) & 3) << 1) | ((r >> 1) & 1); }   // rows 8 a + 4 b + c, a = 0..3, c = 0..3
 
 // C[M][N] = A[M][K] * W[N][K]^T.  Block tile (WM * MI * 16) x (WN * 64), one wave per (MI * 16) x 64 sub-tile:
 //   <MI = 4, WM = 2, WN = 2>: 128 x 128, 256 threads, 64 KiB LDS (2 blocks / CU)  -- any N % 128 == 0
@@ -112,7 +113,10 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
     // of the bf16 epilogues every float4 instruction touched 64 separate cache lines and the address coalescer (not HBM) bound
     // the epilogue: 52 k clocks per tile, more than the projection's K loop.
     constexpr bool NAT = EPI == EPI_RESID_F32;
-#define KEYW(r) (NAT ? key_act(r) : key_w(r))
+    // bf16 epilogues: MFMA row 4 fg + r of n-tile j is weight row 32 (j / 2) + 8 fg + 4 (j % 2) + r: a lane owns 8 consecutive
+    // columns (one 16-byte store) of n-tile pair j / 2 and the four lane groups cover 64 contiguous bytes of the row
+    constexpr bool PAIR = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16;
+#define KEYW(r) (NAT ? key_act(r) : (PAIR ? key_pair(r) : key_w(r)))
     // XCD-aware remap: consecutive tiles along N (sharing the A panel) stay on one XCD's L2
     const int nbn = N / BN;
     const int nbm = (M + BM - 1) / BM;
@@ -167,7 +171,9 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
 #pragma unroll
     for (int i = 0; i < MI; ++i) arow[i] = wm * (MI * 16) + i * 16 + fr;              // activation row (B operand column)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wrow[j] = NAT ? wn * 64 + 16 * j + fr : wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);  // weight row of MFMA row fr in n-tile j
+    for (int j = 0; j < 4; ++j)                   // weight row of MFMA row fr in n-tile j
+        wrow[j] = NAT ? wn * 64 + 16 * j + fr
+                      : (PAIR ? wn * 64 + 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3) : wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3));
     // One K step = 2 * MI groups of 4 MFMAs.  The GA + GW direct-to-LDS pieces of the NEXT tile are issued one at a time
     // between those groups: a piece blocks its wave's issue port for ~100 cycles, and eight of them back to back at the top
     // of the step (right after the barrier, in every wave at once) left the MFMA pipe idle for a third of the step.
@@ -234,6 +240,41 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
                 x.x += (acc[i][j][0] + b4[j].x) * s4[j].x; x.y += (acc[i][j][1] + b4[j].y) * s4[j].y;
                 x.z += (acc[i][j][2] + b4[j].z) * s4[j].z; x.w += (acc[i][j][3] + b4[j].w) * s4[j].w;
                 *o = x;
+            }
+        }
+#ifdef IBL_GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GEMM_STAMP(3);
+#endif
+        return;
+    }
+    if (PAIR) {
+        const int nb = col0 + wn * 64 + 8 * fg;
+        float bb[2][8];
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 b4 = epi.bias ? *reinterpret_cast<const float4*>(epi.bias + nb + 32 * j2 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bb[j2][4 * h] = b4.x; bb[j2][4 * h + 1] = b4.y; bb[j2][4 * h + 2] = b4.z; bb[j2][4 * h + 3] = b4.w;
+            }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = row0 + wm * (MI * 16) + i * 16 + fr;
+            if (row >= M) continue;
+            u16* orow = reinterpret_cast<u16*>(epi.out) + (int64_t)row * epi.ldo + nb;
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    v[t] = acc[i][2 * j2 + (t >> 2)][t & 3] + bb[j2][t];
+                    if (EPI == EPI_BIAS_GELU_BF16) v[t] = gelu_erf(v[t]);
+                }
+                *reinterpret_cast<uint4*>(orow + 32 * j2) =
+                    make_uint4((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16),
+                               (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16), (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16));
             }
         }
 #ifdef IBL_GEMM_STAMPS
