@@ -48,8 +48,7 @@ struct GemmEpi {
     int patches_per_crop;   // P (EPI_PATCH)
 };
 
-constexpr int GBK = 64;
-constexpr int LDS_ROW = GBK * 2;        // 128-byte tile rows, XOR-swizzled 16-byte chunks (no padding)
+constexpr int GBK = 64;                 // K granule every caller guarantees (K % 64 == 0)
 
 // LDS images: a tile row holds 8 chunks of 16 bytes; chunk c of row r lives at chunk c ^ key(r).
 //   activation tile: key = r & 7            (fragment rows are consecutive -> conflict-free ds_read_b128)
@@ -57,6 +56,11 @@ constexpr int LDS_ROW = GBK * 2;        // 128-byte tile rows, XOR-swizzled 16-b
 __device__ __forceinline__ int key_act(int r) { return r & 7; }
 __device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 __device__ __forceinline__ int key_pair(int r) { return (((r >> 3) & 3) << 1) | ((r >> 1) & 1); }   // rows 8 a + 4 b + c, a = 0..3, c = 0..3
+// 64-byte tile rows (BK = 32): 4 chunks per row, four rows per 256-byte bank row; the same three fragment-row maps are
+// conflict-free in every 16-lane ds_read_b128 group with a one-bit key (found by enumeration, tools/lds_keys.py)
+template <int BK> __device__ __forceinline__ int keyx_act(int r) { return BK == 64 ? key_act(r) : ((r >> 2) & 1) << 1; }
+template <int BK> __device__ __forceinline__ int keyx_w(int r) { return BK == 64 ? key_w(r) : ((r >> 4) & 1) << 1; }
+template <int BK> __device__ __forceinline__ int keyx_pair(int r) { return BK == 64 ? key_pair(r) : ((r >> 3) & 1) << 1; }
 
 // C[M][N] = A[M][K] * W[N][K]^T.  Block tile (WM * MI * 16) x (WN * 64), one wave per (MI * 16) x 64 sub-tile:
 //   <MI = 4, WM = 2, WN = 2>: 128 x 128, 256 threads, 64 KiB LDS (2 blocks / CU)  -- any N % 128 == 0
@@ -97,12 +101,14 @@ extern "C" int ibl_gemm_stamps_read(long long* dst, int n) {
 #define GEMM_STAMP(k)
 #endif
 
-template <int EPI, int MI, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
+template <int EPI, int MI, int WM, int WN, int BK, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
                                                                   int64_t ldw, int M, int N, int K, GemmEpi epi) {
     constexpr int BM = WM * MI * 16, BN = WN * 64, NW = WM * WN;
+    constexpr int LDS_ROW = BK * 2;          // bytes per tile row, XOR-swizzled 16-byte chunks (no padding)
+    constexpr int CPR = BK / 8, RPI = 64 / CPR;             // chunks per row; rows per 1 KiB wave instruction
     constexpr int A_BYTES = BM * LDS_ROW, W_BYTES = BN * LDS_ROW, STAGE = A_BYTES + W_BYTES;
-    constexpr int GA = BM / 8 / NW, GW = BN / 8 / NW;       // 8-row groups (1 KiB wave instructions) per wave
+    constexpr int GA = BM / RPI / NW, GW = BN / RPI / NW;   // 1 KiB wave instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
     // bf16 epilogues: MFMA row 4 fg + r of n-tile j is weight row 32 (j / 2) + 8 fg + 4 (j % 2) + r: a lane owns 8 consecutive
     // columns (one 16-byte store) of n-tile pair j / 2 and the four lane groups cover 64 contiguous bytes of the row
     constexpr bool PAIR = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16;
-#define KEYW(r) (NAT ? key_act(r) : (PAIR ? key_pair(r) : key_w(r)))
+#define KEYW(r) (NAT ? keyx_act<BK>(r) : (PAIR ? keyx_pair<BK>(r) : keyx_w<BK>(r)))
     // XCD-aware remap: consecutive tiles along N (sharing the A panel) stay on one XCD's L2
     const int nbn = N / BN;
     const int nbm = (M + BM - 1) / BM;
@@ -133,19 +139,19 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
     const u16* w_src[GW];
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-        const int r = (wave + NW * i) * 8 + (lane >> 3), pch = lane & 7;
+        const int r = (wave + NW * i) * RPI + lane / CPR, pch = lane % CPR;
         int ar = row0 + r;
         if (ar >= M) ar = M - 1;
-        a_src[i] = A + (int64_t)ar * lda + ((pch ^ key_act(r)) << 3);
+        a_src[i] = A + (int64_t)ar * lda + ((pch ^ keyx_act<BK>(r)) << 3);
     }
 #pragma unroll
     for (int i = 0; i < GW; ++i) {
-        const int r = (wave + NW * i) * 8 + (lane >> 3), pch = lane & 7;
+        const int r = (wave + NW * i) * RPI + lane / CPR, pch = lane % CPR;
         w_src[i] = W + (int64_t)(col0 + r) * ldw + ((pch ^ KEYW(r)) << 3);
     }
 #define GEMM_GLDS(buf, kt)                                                                                              \
     do {                                                                                                                \
-        const int64_t _ko = (int64_t)(kt) * GBK;                                                                        \
+        const int64_t _ko = (int64_t)(kt) * BK;                                                                         \
         _Pragma("unroll") for (int _i = 0; _i < GA; ++_i)                                                               \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[_i] + _ko),         \
                                              (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE + (wave + NW * _i) * 1024), 16, 0, 0); \
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / GBK;
+    const int nk = K / BK;
     GEMM_STAMP(0);
     GEMM_GLDS(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,22 +183,22 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
     // One K step = 2 * MI groups of 4 MFMAs.  The GA + GW direct-to-LDS pieces of the NEXT tile are issued one at a time
     // between those groups: a piece blocks its wave's issue port for ~100 cycles, and eight of them back to back at the top
     // of the step (right after the barrier, in every wave at once) left the MFMA pipe idle for a third of the step.
-    constexpr int NG = 2 * MI, NP = GA + GW;
+    constexpr int KS = BK / 32, NG = KS * MI, NP = GA + GW;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
-        const int64_t ko = (int64_t)(kt + 1) * GBK;
+        const int64_t ko = (int64_t)(kt + 1) * BK;
         unsigned char* nxt = smem + (buf ^ 1) * STAGE;
         const unsigned char* pa = smem + buf * STAGE;
         const unsigned char* pw = pa + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int ch = 4 * ks + fg;
             bf16x8 af[MI], wf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + wrow[j] * LDS_ROW + ((ch ^ KEYW(wrow[j])) << 4));
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ key_act(arow[i])) << 4));
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ keyx_act<BK>(arow[i])) << 4));
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -346,23 +352,36 @@ __global__ __launch_bounds__(WM * WN * 64) void ibl_gemm_bf16_tn(const u16* __re
 #endif
 }
 
-template <int EPI, int MI, int WM, int WN>
+template <int EPI, int MI, int WM, int WN, int BK, int OCC>
 static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     const int nwg = (N / BN) * ((M + BM - 1) / BM);
-    const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW;
+    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI, MI, WM, WN>),
+        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     void* tok;
     ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);
-    hipLaunchKernelGGL((ibl_gemm_bf16_tn<EPI, MI, WM, WN>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
+}
+
+// Tile configurations:
+//   0  256 x 256, BK 64, 8 waves, 128 KiB LDS, 1 block / CU   (fewest operand bytes per FLOP)
+//   1  128 x 128, BK 64, 4 waves,  64 KiB LDS, 2 blocks / CU  (any N % 128 == 0, small M)
+//   2  256 x 128, BK 32, 4 waves,  48 KiB LDS, 2 blocks / CU  (the epilogue of one block overlaps the K loop of the other)
+static int gemm_cfg_override() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("IBL_GEMM_CFG");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
 }
 
 template <int EPI>
@@ -371,10 +390,15 @@ static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int
     if (M <= 0) return IBL_OK;
     if (N % 128 != 0 || K % GBK != 0)
         return ibl_set_error(IBL_ERR_ARG, "gemm: N (%d) must be a multiple of 128 and K (%d) of 64", N, K);
-#ifndef IBL_GEMM_FORCE128
-    if (N % 256 == 0 && M >= 4096) return launch_gemm_cfg<EPI, 8, 2, 4>(A, lda, W, ldw, M, N, K, epi, s);
+    int cfg = (N % 256 == 0 && M >= 4096) ? 0 : 1;
+    const int ov = gemm_cfg_override();
+    if (ov == 1 || ov == 2 || (ov == 0 && N % 256 == 0)) cfg = ov;
+#ifdef IBL_GEMM_FORCE128
+    cfg = 1;
 #endif
-    return launch_gemm_cfg<EPI, 4, 2, 2>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 0) return launch_gemm_cfg<EPI, 8, 2, 4, 64, 1>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 2) return launch_gemm_cfg<EPI, 8, 2, 2, 32, 2>(A, lda, W, ldw, M, N, K, epi, s);
+    return launch_gemm_cfg<EPI, 4, 2, 2, 64, 2>(A, lda, W, ldw, M, N, K, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------------
