@@ -5,10 +5,12 @@ Workload (BASELINE.json configs[1], "C2"): DINOv2 ViT-B/14 crops (224^2, Q = 7 p
 memory (E = 4 stored embeddings each, 5 000-point coloured clouds), FPFH + RANSAC + coloured ICP on the
 5k-point clouds of every candidate assignment, whole-memory evaluation.  A "step" is one pass of the hot path
 (ObjectMemory.localise body, object_memory.py:911-1131) over one batch of --frames synthetic query frames whose
-crops and detected clouds are already resident in HBM.  Synthetic data and seeded random-init weights
-(no datasets / checkpoints offline).
+crops and detected clouds are already resident in HBM.  Consecutive steps are pipelined the way a localisation service runs
+(LocaliseEngine.localise_stream: embed + match of step k + 1 on a second HIP stream while step k is assigned and registered;
+--sequential runs them back to back); all work of the K timed steps happens inside the timed region.  Synthetic data and
+seeded random-init weights (no datasets / checkpoints offline).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -153,8 +155,8 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32, help="query frames per step and per GPU")
     ap.add_argument("--memory", type=int, default=1000)
     ap.add_argument("--views", type=int, default=4)
@@ -164,6 +166,7 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--arena-gb", type=float, default=24.0)
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--sequential", action="store_true", help="run the steps back to back instead of pipelined")
     ap.add_argument("--profile-kernel", default="", help="(internal) name of the kernel the roofline is reported for")
     args = ap.parse_args()
 
@@ -190,16 +193,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        run_step(eng, batches[i], args)
+    kw = dict(fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
+
+    def stream_items(lo, hi):
+        return [dict(det=b["det"], q_per_frame=b["qs"], crops=b["crops"], seed=args.seed) for b in batches[lo:hi]]
+
+    if args.sequential:
+        for i in range(args.warmup):
+            run_step(eng, batches[i], args)
+    else:
+        for _ in eng.localise_stream(stream_items(0, args.warmup), **kw):
+            pass
     barrier()
     from ibloc_amd import prof
     prof.reset(enable=os.environ.get("IBL_BENCH_NOPROF", "") == "")
     timings = {}
     t0 = time.perf_counter()
     ok = 0
-    for i in range(args.steps):
-        res = run_step(eng, batches[args.warmup + i], args, timings=timings)
+    # A step = one batch of frames through embed -> match -> assign -> register -> evaluate -> pose.  Consecutive steps are
+    # pipelined (LocaliseEngine.localise_stream: embed + match of step k + 1 on a second stream while step k is assigned and
+    # registered); every step's work starts and ends inside the timed region.  --sequential runs them back to back.
+    if args.sequential:
+        step_results = (run_step(eng, batches[args.warmup + i], args, timings=timings) for i in range(args.steps))
+    else:
+        step_results = eng.localise_stream(stream_items(args.warmup, args.warmup + args.steps), **kw)
+    for i, res in enumerate(step_results):
         b = batches[args.warmup + i]
         for f, r in enumerate(res):
             P = b["poses"][f]
@@ -212,6 +230,13 @@ def main():
         dt = float(t.item())
     total_frames = args.frames * args.steps * world_size
     value = total_frames / dt
+    roof_live = prof.roofline(None)                       # before the untimed stage-timing step below adds launches
+    roof_iso = None
+    if not args.sequential:                               # per-stage device times of one step run back to back, outside the timed region
+        prof.reset(enable=os.environ.get("IBL_BENCH_NOPROF", "") == "")
+        run_step(eng, batches[args.warmup + args.steps - 1], args, timings=timings)
+        torch.cuda.synchronize()
+        roof_iso = prof.roofline(None)                    # the same GEMM launches with nothing else on the device
 
     if rank == 0:
         # HBM traffic per GEMM launch: PMC counters cannot be read in-process, so the figure comes from the committed
@@ -220,7 +245,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01", "gemm_pmc.json")
         if os.path.exists(pmc) and (args.model, args.frames, args.q, args.memory) == ("dinov2_vitb14", 32, 7, 1000):
             traffic = json.load(open(pmc)).get("gemm_traffic_bytes_per_launch")
-        roof = prof.roofline(traffic)
+        roof = roof_live
+        for r in (roof, roof_iso):
+            if r is not None:
+                r["traffic"] = traffic
         cpu = None
         if args.cpu_frames > 0 and world_size == 1:       # the CPU leg is timed on rank 0 of the single-GPU run only
             v, cdt, threads = cpu_baseline(args, world, mem_emb, batches[args.warmup], args.cpu_frames)
@@ -244,9 +272,14 @@ def main():
                        f"(Q={args.q}), {args.memory}-instance memory (E={args.views}), FPFH+RANSAC+coloured ICP on {args.points}-pt clouds, "
                        "whole-memory evaluate", "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
                        "points_per_object": args.points, "encoder": args.model, "parallelism": f"frames-dp{world_size}"},
+            # `roofline`: HIP events around every GEMM launch of the timed region.  With pipelined steps the embed stream shares the
+            # device with the registration kernels of the previous step, so a launch's duration there is not the kernel's own
+            # speed; `roofline_isolated` is the same measurement over the launches of one extra step run alone afterwards.
             "roofline": roof,
+            "roofline_isolated": roof_iso,
             "cpu_baseline": cpu,
-            "stage_ms_per_step": {k: v / args.steps for k, v in timings.items() if isinstance(v, float)},
+            "pipelined_steps": not args.sequential,
+            "stage_ms_per_step": {k: v / (args.steps if args.sequential else 1) for k, v in timings.items() if isinstance(v, float)},
             "localised_within_0.6m": ok / max(1, args.frames * args.steps),
             # last step: points whose normals/FPFH/gradients came from the resident instance features, points recomputed in the
             # context of their job (instances within the influence radius of each other), recomputed groups, job sides

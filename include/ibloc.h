@@ -329,6 +329,30 @@ int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int
                               double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, int64_t* reuse_stats_out,
                               void* stream);
 
+/* ---- memory build / consolidation; fp64 clouds, as the build side of the reference keeps them ---- */
+
+/* Voxel down-sampling with colours of every object of a batch.  Replaces voxel_down_sample_with_colors
+ * (utils/depth_utils.py:211-265) as applied per object by ObjectInfo.downsample (object_memory/object_info.py:95-97) <-
+ * ObjectMemory.downsample_all_objects (object_memory/object_memory.py:258-263): voxel = floor(p / voxel_size) per axis, output
+ * voxels in order of first occurrence, point / colour = running fp64 sum in input order / count (bit-identical to np.mean).
+ *   points, colors [dev] N x 3 doubles (colors may be NULL); seg_off_host [HOST] n_seg + 1 object offsets (n_seg <= 65535, an
+ *   object may span at most 65536 voxels per axis); out_points / out_colors [dev] N x 3 doubles (the first
+ *   out_seg_off_host[n_seg] rows are written); out_counts [dev] N ints or NULL (points per voxel); out_seg_off_host [HOST]
+ *   n_seg + 1.  The call synchronises. */
+int ibl_voxel_downsample_batch(ibl_reg_ctx* ctx, const double* points, const double* colors, const int32_t* seg_off_host, int32_t n_seg,
+                               double voxel_size, double* out_points, double* out_colors, int32_t* out_counts,
+                               int32_t* out_seg_off_host, void* stream);
+
+/* DBSCAN labels, one independent clustering per group of a batch of concatenated clouds.  Replaces
+ * open3d.geometry.PointCloud.cluster_dbscan(eps, min_points) as called by recluster_objects_with_dbscan
+ * (object_memory/object_memory.py:300-305) and per agglomerative cluster by recluster_via_clustering_and_IoU (:627-631):
+ * neighbours are the points at squared distance < eps^2 (the point itself included), a core point has >= min_points of them,
+ * clusters are numbered from 0 per group in the order a sequential scan meets their first core point, a border point takes the
+ * lowest-numbered cluster among its core neighbours, every other point is -1.
+ *   points [dev] N x 3 doubles; grp_off_host [HOST] n_grp + 1; labels [dev] N ints; n_clusters_host [HOST] n_grp or NULL. */
+int ibl_dbscan_batch(ibl_reg_ctx* ctx, const double* points, const int32_t* grp_off_host, int32_t n_grp, double eps, int32_t min_points,
+                     int32_t* labels, int32_t* n_clusters_host, void* stream);
+
 /* Persistent spatial hash over ALL memory points (world frame), built once per memory upload from the
  * context arena.  Replaces the KD-tree Open3D rebuilds over `all_memory_pcd` on every evaluate_registration
  * call (utils/fpfh_register.py:146-148 <- object_memory/object_memory.py:1104).  cell >= 2 * threshold keeps a

@@ -54,6 +54,8 @@ _SIGS = {
     "ibl_reg_ctx_status": (C.c_int, [vp, C.c_int]),
     "ibl_unproject_masks": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, vp, C.c_int64,
                                       vp, vp, vp]),
+    "ibl_voxel_downsample_batch": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_double, vp, vp, vp, vp, vp]),
+    "ibl_dbscan_batch": (C.c_int, [vp, vp, vp, C.c_int32, C.c_double, C.c_int32, vp, vp, vp]),
     "ibl_radius_outlier_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp]),
     "ibl_normals_fpfh_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp]),
     "ibl_register_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,

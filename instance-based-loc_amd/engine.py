@@ -72,16 +72,68 @@ class LocaliseEngine:
         self.assign_threads = assign_threads or min(os.cpu_count() or 1, 16)
         self.reuse_features = True      # False: every assignment recomputes its features (same results, the reference's schedule)
         self._pool = ThreadPoolExecutor(max_workers=1)
+        self._pool_a = None             # stage-A worker of localise_stream
 
     def _det_features(self, clean, voxel_size):
         torch.cuda.set_device(clean.pts4.device)          # worker thread: the current device is per thread
         return instance_features_batch(self.ctx, clean, voxel_size)
 
+    def _embed_match(self, crops, det_emb, tick=lambda name: None, to_host=True):
+        """Stage A: embed + match on the current stream -> fp16 similarity rows (one row per detection, M + 1 columns)."""
+        mem = self.memory
+        if det_emb is None:
+            if self.encoder is None:
+                raise ValueError("no encoder: pass det_emb")
+            det_emb = self.encoder.embed(crops)
+        else:
+            det_emb = torch.as_tensor(det_emb, dtype=torch.float32, device=mem.device).contiguous()
+        tick("embed")
+        # Q > M truncates the detections that are matched (object_memory.py:918-920)
+        detn = match.normalize_rows(det_emb)                                        # :924
+        _, aug = match.closest_similarity(detn, mem.mem_emb, mem.emb_offsets, want_sims=False, want_aug=True)   # :933-936, sim_volume :13-18
+        tick("match")
+        return aug.cpu().numpy() if to_host else aug
+
+    def localise_stream(self, batches, **kw):
+        """Pipelined form of `localise_batch` for a sequence of frame batches (dicts with det, q_per_frame and crops or det_emb,
+        optionally seed / job_id_base): embed + match of batch k + 1 run on a second stream, driven by a worker thread, while batch
+        k is assigned (host) and registered; results are those of `localise_batch`, yielded in order.  The two stages touch
+        disjoint state: the encoder / match workspaces belong to stage A, the registration arena to stage B."""
+        dev = self.memory.mem_emb.device
+        side = torch.cuda.Stream(device=dev)      # equal priority: raising either stage's stream priority measured 7-8 % slower
+        side.wait_stream(torch.cuda.current_stream(dev))      # inputs (crops, memory) were produced on the caller's stream
+
+        def stage_a(b):
+            torch.cuda.set_device(dev)                      # worker thread: current device and stream are per thread
+            with torch.cuda.stream(side):
+                return self._embed_match(b.get("crops"), b.get("det_emb"))
+
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return
+        if self._pool_a is None:
+            self._pool_a = ThreadPoolExecutor(max_workers=1)
+        fut = self._pool_a.submit(stage_a, cur)
+        while cur is not None:
+            aug_h = fut.result()
+            nxt = next(it, None)
+            if nxt is not None:
+                fut = self._pool_a.submit(stage_a, nxt)
+            args = dict(kw)
+            for k in ("seed", "job_id_base"):
+                if k in cur:
+                    args[k] = cur[k]
+            yield self.localise_batch(cur["det"], cur["q_per_frame"], aug_h=aug_h, **args)
+            cur = nxt
+
     def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
                        fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, outlier_radius=0.05, outlier_nb_points=8,
-                       seed=0, job_id_base=0, ransac_max_iter=4000000, num_per_length=4, eval_threshold=None, timings=None):
+                       seed=0, job_id_base=0, ransac_max_iter=4000000, num_per_length=4, eval_threshold=None, timings=None,
+                       aug_h=None):
         """det: detected clouds of all frames (segments in frame order, <= 7 per frame); crops: uint8 tensor
-        (sum Q, H, W, 3) or list of arrays, or det_emb: (sum Q, D) precomputed embeddings."""
+        (sum Q, H, W, 3) or list of arrays, or det_emb: (sum Q, D) precomputed embeddings (or aug_h: the host similarity rows
+        stage A of `localise_stream` produced)."""
         mem = self.memory
         q_per_frame = np.asarray(q_per_frame, dtype=np.int32)
         F = len(q_per_frame)
@@ -97,17 +149,7 @@ class LocaliseEngine:
 
         tick("start")
         # ---- embed + match (GPU) -------------------------------------------------------------------
-        if det_emb is None:
-            if self.encoder is None:
-                raise ValueError("no encoder: pass det_emb")
-            det_emb = self.encoder.embed(crops)
-        else:
-            det_emb = torch.as_tensor(det_emb, dtype=torch.float32, device=mem.device).contiguous()
-        tick("embed")
-        # Q > M truncates the detections that are matched (object_memory.py:918-920)
-        detn = match.normalize_rows(det_emb)                                        # :924
-        _, aug = match.closest_similarity(detn, mem.mem_emb, mem.emb_offsets, want_sims=False, want_aug=True)   # :933-936, sim_volume :13-18
-        tick("match")
+        aug = self._embed_match(crops, det_emb, tick, to_host=False) if aug_h is None else None
         # ---- clean the detected clouds (:992-998) ---------------------------------------------------
         keep = radius_outlier_batch(self.ctx, det, outlier_radius, outlier_nb_points)
         keepb = keep.bool()
@@ -117,7 +159,8 @@ class LocaliseEngine:
         clean_pts = det.pts4[keepb].contiguous()
         tick("outlier")
         # ---- one host round trip: fp16 similarity rows + cleaned sizes ------------------------------
-        aug_h = aug.cpu().numpy()
+        if aug_h is None:
+            aug_h = aug.cpu().numpy()
         new_off_h = new_off.cpu().numpy().astype(np.int32)
         clean = CloudBatch(clean_pts, new_off_h)
         tick("d2h")

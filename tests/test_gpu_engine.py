@@ -152,3 +152,41 @@ def test_full_size_properties():
     assert tm["reuse"][0] > 0 and len(mem._features) == 1                                              # (4)
     assert ctx.status() & 1 == 0
     ctx.close()
+
+
+def test_pipelined_stream_equals_batch_by_batch():
+    """LocaliseEngine.localise_stream (embed + match of the next batch on a second stream while the current one registers)
+    yields exactly what localise_batch returns batch by batch, with a real encoder in stage A"""
+    import torch
+    from ibloc_amd import vit as V
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+    from ibloc_amd.registration import CloudBatch, RegContext
+    from ibloc_amd.synth import SynthWorld
+    cfg = V.CONFIGS["tiny_dino"]
+    enc = V.VitEncoder(cfg, V.random_weights(cfg, 4), device="cuda")
+    rng = np.random.default_rng(71)
+    M = 10
+    base = rng.integers(0, 255, size=(M, 2, 40, 36, 3), dtype=np.uint8)          # two views per memory object
+    mem_emb = enc.embed(torch.from_numpy(base.reshape(M * 2, 40, 36, 3)).cuda()).cpu().numpy().reshape(M, 2, -1)
+    w = SynthWorld(M, pts_per_object=2000, E=2, D=mem_emb.shape[-1], seed=72)
+    ctx = RegContext(6 << 30)
+    mem = MemoryShard(ctx, [mem_emb[i] for i in range(M)], w.points, colors=w.colors)
+    batches = []
+    for b in range(4):
+        frames = [w.make_frame(rng, q=3, pts_per_object=2000) for _ in range(2)]
+        clouds = [c[0] for f in frames for c in f["clouds"]]
+        ints = [intensity_from_colors(c[1]) for f in frames for c in f["clouds"]]
+        ids = [i for f in frames for i in f["ids"]]
+        crops = np.stack([np.clip(base[i, b % 2].astype(np.int16) + rng.integers(-6, 7, size=(40, 36, 3)), 0, 255).astype(np.uint8) for i in ids])
+        batches.append(dict(det=CloudBatch.from_numpy(clouds, ints), q_per_frame=[3, 3], crops=torch.from_numpy(crops).cuda(), seed=9 + b))
+    eng = LocaliseEngine(mem, enc)
+    kw = dict(fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5)
+    one = [eng.localise_batch(b["det"], b["q_per_frame"], crops=b["crops"], seed=b["seed"], **kw) for b in batches]
+    piped = list(eng.localise_stream(batches, **kw))
+    assert len(piped) == len(one) == 4
+    for ra, rb in zip(one, piped):
+        for a, b in zip(ra, rb):
+            assert a.assignments == b.assignments and a.best == b.best and len(a.assignments) > 0
+            assert np.array_equal(a.pose, b.pose) and np.array_equal(a.pose_corrected, b.pose_corrected)
+    assert list(eng.localise_stream([], **kw)) == []
+    ctx.close()
