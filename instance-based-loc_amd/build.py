@@ -73,3 +73,65 @@ def dbscan_batch(ctx: RegContext, groups, eps, min_points, device="cuda"):
     _lib.check(st, "ibl_dbscan_batch")
     h = labels[:n].cpu().numpy()
     return [h[off[i]:off[i + 1]] for i in range(len(sizes))], n_clusters[:len(sizes)].copy()
+
+
+# ---- host helpers of the consolidation step ----------------------------------------------------------------------------------
+_default_ctx = None
+
+
+def default_ctx():
+    """Arena for stand-alone calls (ObjectInfo.downsample outside an ObjectMemory)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = RegContext(1 << 30)
+    return _default_ctx
+
+
+def _rows(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, 3) + 0.0)      # -0.0 == 0.0 like the elementwise test
+    return a.view([("x", np.float64), ("y", np.float64), ("z", np.float64)]).ravel()
+
+
+def clusters_of_first_points(all_points, labels, first_points):
+    """object_memory.py:318-333 / :638-649: an object joins the cluster that contains a point EQUAL to its first point; when
+    several clusters do, the highest label wins (the reference loops over the labels in ascending order and overwrites).
+    Returns (assignment per object, number of objects that matched more than one label)."""
+    labels = np.asarray(labels)
+    av, qv = _rows(all_points), _rows(first_points)
+    out = np.full(len(qv), -1, dtype=np.int64)
+    hit = np.isin(av, qv) & (labels >= 0)
+    multi = 0
+    if hit.any():
+        rows, labs = av[hit], labels[hit]
+        for i, q in enumerate(qv):
+            m = labs[rows == q]
+            if len(m):
+                out[i] = m.max()
+                multi += len(np.unique(m)) > 1
+    return out, multi
+
+
+def merge_objects_by_cluster(objects, assignments, n_clusters):
+    """object_memory.py:339-362 / :652-667: per label in ascending order, the objects assigned to it are folded into the first
+    one with ObjectInfo.__add__; labels nobody was assigned to produce nothing; unassigned objects (-1) are dropped."""
+    merged = []
+    for label in range(int(n_clusters)):
+        group = [objects[i] for i in range(len(objects)) if assignments[i] == label]
+        if not group:
+            continue
+        acc = group[0]
+        for other in group[1:]:
+            acc = acc + other
+        merged.append(acc)
+    return merged
+
+
+def transform_points(points, pose):
+    """utils/depth_utils.py:92-116 on an (N, 3) array: pose = x y z qx qy qz qw; the quaternion slice is normalised IN PLACE like
+    the reference (`q /= norm` on a view of the caller's pose)."""
+    from scipy.spatial.transform import Rotation
+    t = pose[:3]
+    q = pose[3:]
+    q /= np.linalg.norm(q)
+    R = Rotation.from_quat(q).as_matrix()
+    return (R @ np.asarray(points).T).T + t

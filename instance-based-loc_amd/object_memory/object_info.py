@@ -32,17 +32,64 @@ class ObjectInfo:
         if new_name not in self.names:
             self.names.append(new_name)
 
-    def __add__(self, other):
-        for n in other.names:
+    def _add_names(self, new_names):
+        for n in new_names:
             self._add_name(n)
-        self.embeddings += other.embeddings
-        pts = np.vstack((np.asarray(self.pointcloud.points), np.asarray(other.pointcloud.points)))
+
+    def _add_embedding(self, new_emb):
+        """object_info.py:40-59: below the cap append; at the cap the second-nearest stored embedding is replaced when its own
+        nearest neighbour is closer than its distance to the new one (sklearn NearestNeighbors, as the reference)."""
+        if len(self.embeddings) < self.max_embeddings_num:
+            self.embeddings.append(new_emb)
+            return
+        from sklearn.neighbors import NearestNeighbors
+        arr = np.array(self.embeddings)
+        knn = NearestNeighbors(n_neighbors=2, metric="euclidean")
+        knn.fit(arr)
+        distances, indices = knn.kneighbors(np.asarray(new_emb).reshape(1, -1), n_neighbors=2)
+        j = indices[0][1]
+        if knn.kneighbors(arr[j].reshape(1, -1), n_neighbors=1)[0][0][0] < distances[0][1]:
+            self.embeddings[j] = new_emb
+
+    def _add_embeddings(self, new_embs):
+        self.embeddings += new_embs
+
+    def _add_pointcloud(self, new_pointcloud):
+        pts = np.vstack((np.asarray(self.pointcloud.points), np.asarray(new_pointcloud.points)))
         cols = None
-        if self.pointcloud.colors is not None and other.pointcloud.colors is not None:
-            cols = np.vstack((np.asarray(self.pointcloud.colors), np.asarray(other.pointcloud.colors)))
+        if self.pointcloud.colors is not None and new_pointcloud.colors is not None:
+            cols = np.vstack((np.asarray(self.pointcloud.colors), np.asarray(new_pointcloud.colors)))
         self.pointcloud = Cloud(pts, cols)
         self._process_pointcloud()
-        return self
+
+    def __add__(self, other):
+        self._add_names(other.names)
+        self._add_embeddings(other.embeddings)
+        self._add_pointcloud(other.pointcloud)
+        return self                      # means are NOT refreshed here (object_info.py:89-93); callers do it where the reference does
+
+    def downsample(self, voxel_size, ctx=None):
+        """object_info.py:95-97 -> utils/depth_utils.py:211-265, on the device (bit-identical; ObjectMemory.downsample_all_objects
+        does all objects in one call)."""
+        from ibloc_amd.build import default_ctx, voxel_downsample_batch
+        pts, cols = voxel_downsample_batch(ctx or default_ctx(), [self.pointcloud.points],
+                                           [self.pointcloud.colors] if self.pointcloud.colors is not None else None, voxel_size)
+        self.pointcloud = Cloud(pts[0], cols[0] if cols is not None else None)
+        self._process_pointcloud()
+
+    def add_info(self, new_name, new_emb, new_pointcloud, align=False, max_iteration=30, max_correspondence_distance=0.01):
+        if align:
+            raise NotImplementedError("Aligning is a To-Do")
+        self._add_name(new_name)
+        self._add_embedding(new_emb)
+        self._add_pointcloud(new_pointcloud if isinstance(new_pointcloud, Cloud) else Cloud(np.asarray(new_pointcloud.points), np.asarray(new_pointcloud.colors)))
+        self._compute_means()
+
+    def update_pointcloud_with_mask(self, mask):
+        mask = np.asarray(mask)
+        cols = self.pointcloud.colors[mask, :] if self.pointcloud.colors is not None else None
+        self.pointcloud = Cloud(self.pointcloud.points[mask, :], cols)
+        self._process_pointcloud()
 
     # ---- persistence: the reference's per-object directory layout (object_info.py:109-118) --------------------------
     def save(self, save_directory: str):

@@ -5,9 +5,11 @@
 crops to the returned pose runs through the batched HIP engine (ibloc_amd.engine).  The perception front end
 (RAM + GroundingDINO + SAM, object_memory/object_finder.py) is out of scope for this build: pass any callable with
 the reference's `ObjectFinder.find` contract as `object_finder=` (find(rgb_path, consider_floor) ->
-(grounded_imgs, bounding_boxes, masks, phrases) or (None, None, None, None)).  Memory construction
-(process_image / reclustering) is offline and also out of scope; `add_object()` / `load_objects()` fill the memory
-with (name, embeddings, cloud) records in the reference's ObjectInfo layout.
+(grounded_imgs, bounding_boxes, masks, phrases) or (None, None, None, None)).  Memory construction mirrors
+`process_image`, `downsample_all_objects`, `remove_points_below_floor`, `recluster_objects_with_dbscan`, `_recluster_IoU` and
+`recluster_via_clustering_and_IoU`: voxel down-sampling and DBSCAN run on the device (ibloc_amd.build), agglomerative clustering
+is scikit-learn's as in the reference, and the object-aligned IoU (Open3D OBB + Objectron, third-party) is passed in as
+`iou_func`.  `add_object()` / `load()` fill the memory with (name, embeddings, cloud) records in the reference's ObjectInfo layout.
 """
 import os
 
@@ -70,6 +72,8 @@ class ObjectMemory():
         self.load_rgb_image_func = load_rgb_image_func
         self.load_depth_image_func = load_depth_image_func
         self.object_finder = object_finder
+        self.dataset_floor_thickness = dataset_floor_thickness
+        self.iou_func = None            # (points_i, points_j) -> IoU for _recluster_IoU; the reference's Objectron IoU is third-party
         self.memory = []
         self.floors = None
         self._ctx = RegContext(arena_bytes)
@@ -87,6 +91,146 @@ class ObjectMemory():
         info.embeddings = embs
         info._compute_means()
         self.memory.append(info)
+        self._engine = None
+
+    # ---- memory build (object_memory.py:163-256) ----------------------------------------------------------
+    def _log(self, *a):
+        if self.log_enabled:
+            print(*a)
+
+    def process_detections(self, obj_phrases, embs, obj_clouds, pose, add_noise=False, pose_noise={'trans': 0.0005, 'rot': 0.0005},
+                           depth_noise=0.003, min_points=500):
+        """process_image after perception (:187-256): obj_clouds = [(points (N, 3), colors (N, 3)), ...] in the camera frame, pose =
+        x y z qx qy qz qw (its quaternion slice is normalised in place, as the reference's transform_pointcloud does)."""
+        from ibloc_amd.build import transform_points
+        from .object_finder_phrases import check_if_floor
+        if add_noise:
+            pose[:3] = pose[:3] + np.random.normal(0, pose_noise['trans'], pose[:3].shape)
+            q = pose[3:] + np.random.normal(0, pose_noise['rot'], pose[3:].shape)
+            nq = np.linalg.norm(q)
+            pose[3:] = q if nq == 0 else q / nq
+            obj_clouds = [(np.asarray(p) + np.random.normal(0, depth_noise, np.asarray(p).shape), c) for p, c in obj_clouds]
+        for phrase, emb, (p, c) in zip(obj_phrases, embs, [(transform_points(p, pose), c) for p, c in obj_clouds]):
+            if len(p) < min_points:
+                self._log(f"\t\tSkipping as number of points {len(p)} < min_points = {min_points}.")
+                continue
+            info = ObjectInfo(len(self.memory), phrase, emb, Cloud(p, c), self.object_info_max_embeddings_num)
+            if check_if_floor(info.names):
+                self.floors = info if self.floors is None else self.floors + info
+            else:
+                self.memory.append(info)
+        self._engine = None
+
+    def process_image(self, rgb_image_path, depth_image_path, pose, consider_floor, outlier_removal_config=DEFAULT_OUTLIER_REMOVAL_CONFIG,
+                      add_noise=False, pose_noise={'trans': 0.0005, 'rot': 0.0005}, depth_noise=0.003, min_points=500,
+                      will_cluster_later=True, depth_factor=1.):
+        if not will_cluster_later:
+            raise NotImplementedError("Only final clustering available currently")                     # :233-234
+        obj_phrases, embs, obj_clouds = self._get_object_info(rgb_image_path, depth_image_path, consider_floor, outlier_removal_config,
+                                                              depth_factor=depth_factor, for_build=True)
+        if obj_phrases is None:
+            self._log("ObjectMemory.process_image did NOT find any objects")
+            return
+        self.process_detections(obj_phrases, embs, obj_clouds, pose, add_noise, pose_noise, depth_noise, min_points)
+
+    def downsample_all_objects(self, voxel_size):
+        """:258-263 -- every object (and the floor) in ONE device call (ibl_voxel_downsample_batch), bit-identical to the python loop"""
+        from ibloc_amd.build import voxel_downsample_batch
+        objs = list(self.memory) + ([self.floors] if self.floors is not None else [])
+        if not objs:
+            return
+        have_cols = all(o.pointcloud.colors is not None for o in objs)
+        pts, cols = voxel_downsample_batch(self._ctx, [o.pointcloud.points for o in objs],
+                                           [o.pointcloud.colors for o in objs] if have_cols else None, voxel_size, device=self._device())
+        for i, o in enumerate(objs):
+            o.pointcloud = Cloud(pts[i], cols[i] if cols is not None else None)
+            o._process_pointcloud()
+        self._engine = None
+
+    def remove_points_below_floor(self):
+        """:265-293, including its list-mutation-while-iterating behaviour"""
+        floor_height = float('inf')
+        for info in self.memory:
+            floor_height = min(np.min(info.pcd[1, :]), floor_height)
+        for info in self.memory:
+            info.update_pointcloud_with_mask(info.pcd[1, :] > floor_height + self.dataset_floor_thickness)
+            if len(info.pointcloud.points) == 0:
+                self.memory.remove(info)
+        self._engine = None
+
+    def _device(self):
+        return self.device if str(self.device) != "cuda" else "cuda:0"
+
+    def _dbscan_merge(self, groups, eps, min_points):
+        """DBSCAN of each group's concatenated points (one device call for all groups), objects -> clusters by their first point,
+        merge per cluster (:305-362 and :627-670)"""
+        from ibloc_amd.build import clusters_of_first_points, dbscan_batch, merge_objects_by_cluster
+        clouds = [np.concatenate([o.pcd for o in g], axis=-1).T for g in groups]
+        labels, ncl = dbscan_batch(self._ctx, clouds, eps, min_points, device=self._device())
+        out = []
+        for g, pts, lab, k in zip(groups, clouds, labels, ncl):
+            assn, multi = clusters_of_first_points(pts, lab, np.stack([o.pcd[:, 0] for o in g]))
+            if multi:
+                self._log("\t\tMULTIPLE LABELS IN COMBINED RECLUSTERING")
+            out.append(merge_objects_by_cluster(g, assn, k))
+        return out
+
+    def recluster_objects_with_dbscan(self, eps=0.2, min_points_per_cluster=300, visualize=False):
+        self._log("Clustering using DBSCAN")
+        self.memory = self._dbscan_merge([list(self.memory)], eps, min_points_per_cluster)[0] if self.memory else []
+        for i, o in enumerate(self.memory):
+            o.id = i
+        self._engine = None
+
+    def _recluster_IoU(self, IoU_threshold=0.6, iou_func=None):
+        """:710-747: average-linkage agglomerative clustering on 1 - IoU.  iou_func(points_i, points_j): the reference uses the
+        object-aligned Objectron IoU (third-party, not in this build, see utils/IoU_ops.py); ObjectMemory.iou_func is the default."""
+        from sklearn.cluster import AgglomerativeClustering
+        iou_func = iou_func or self.iou_func
+        if iou_func is None:
+            from ibloc_amd.utils.IoU_ops import calculate_obj_aligned_3d_IoU as iou_func
+        n = len(self.memory)
+        IoUs = np.zeros((n, n))
+        for i in range(n):
+            for j in range(i, n):
+                IoUs[i][j] = 1 if i == j else 1 - iou_func(np.asarray(self.memory[i].pointcloud.points), np.asarray(self.memory[j].pointcloud.points))
+                IoUs[j][i] = IoUs[i][j]
+        self._log("Clustering agglomeratively")
+        labels = AgglomerativeClustering(n_clusters=None, distance_threshold=1 - IoU_threshold, metric='precomputed', linkage='average').fit(IoUs).labels_
+        new_memory = [None for _ in set(labels)]
+        for lab, obj in zip(labels, self.memory):
+            new_memory[lab] = obj if new_memory[lab] is None else new_memory[lab] + obj
+        self.memory = new_memory
+        for i, o in enumerate(self.memory):
+            o.id = i
+            o._compute_means()
+        self._engine = None
+
+    def recluster_via_clustering_and_IoU(self, distance_func=None, embedding_distance_threshold=0.4, eps=0.4, min_points_per_cluster=150,
+                                         IoU_threshold=0.25, iou_func=None):
+        """:562-708: IoU merge, then average-linkage clustering of the mean embeddings on the reference's rescaled
+        `1 - normalised cosine distance` matrix, then DBSCAN inside every embedding cluster (all clusters in one device call)."""
+        from sklearn.cluster import AgglomerativeClustering
+        self._recluster_IoU(IoU_threshold, iou_func)
+
+        def df(all_obj_embs, all_obj_centroids):
+            normalized = all_obj_embs / np.linalg.norm(all_obj_embs, axis=1, keepdims=True)
+            return 1 - np.dot(normalized, normalized.T)
+
+        embs = np.array([o.mean_emb for o in self.memory])
+        cents = np.array([o.centroid for o in self.memory])
+        D = (distance_func or df)(embs, cents)
+        D -= np.min(D)
+        D /= np.max(D)
+        D = 1 - D
+        self._log("Clustering agglomeratively")
+        labels = AgglomerativeClustering(n_clusters=None, distance_threshold=embedding_distance_threshold, metric='precomputed',
+                                         linkage='average').fit(D).labels_
+        self._log(f"{len(set(labels))} clusters initially")
+        groups = [[o for i, o in enumerate(self.memory) if labels[i] == u] for u in set(labels)]
+        self.memory = [o for merged in self._dbscan_merge(groups, eps, min_points_per_cluster) for o in merged]
+        for i, o in enumerate(self.memory):
+            o.id = i
         self._engine = None
 
     # ---- persistence: the reference's pickle layout (object_memory.py:779-846) -----------------------------
@@ -161,7 +305,7 @@ class ObjectMemory():
         return self._engine
 
     # ---- query ------------------------------------------------------------------------------------------
-    def _get_object_info(self, rgb_image_path, depth_image_path, consider_floor, outlier_removal_config, depth_factor=1.):
+    def _get_object_info(self, rgb_image_path, depth_image_path, consider_floor, outlier_removal_config, depth_factor=1., for_build=False):
         """object_memory.py:125-161: one get_embeddings_func call per detected object, depth -> coloured clouds per mask."""
         if self.object_finder is None:
             raise RuntimeError("no object_finder: the RAM/GroundingDINO/SAM front end is outside this build; pass object_finder=")
@@ -188,8 +332,24 @@ class ObjectMemory():
             d_t = torch.from_numpy(d_np.astype(np.float64)).to(dev)
         clouds = unproject_masks(self._ctx, d_t, torch.from_numpy(np.array(rgb, dtype=np.uint8)).to(dev), (m_t != 0).to(dev),
                                  self.camera_focal_lenth_x, self.camera_focal_lenth_y, depth_factor)
+        keep = None
         if outlier_removal_config is not None and clouds.n > 0:
             keep = radius_outlier_batch(self._ctx, clouds, outlier_removal_config["radius"], outlier_removal_config["radius_nb_points"])
+        if for_build:
+            # memory build: (points, colours) per object on the host, colours = float32 rgb / 255 of the surviving pixels
+            # (utils/depth_utils.py:73-80); coordinates are those of the HBM layout (float32)
+            pts = clouds.pts4[:, :3].double().cpu().numpy()
+            kh = keep.bool().cpu().numpy() if keep is not None else np.ones(clouds.n, dtype=bool)
+            rgbf = (np.asarray(rgb).astype(np.float32) / 255.0).reshape(-1, 3)
+            m_h = (m_t != 0).reshape(len(masks), -1).numpy() if len(masks) else np.zeros((0, d_np.size), dtype=bool)
+            out = []
+            off = clouds.seg_off_host
+            for i in range(len(masks)):
+                valid = m_h[i] & (d_np.reshape(-1) != 0)
+                k = kh[off[i]:off[i + 1]]
+                out.append((pts[off[i]:off[i + 1]][k], rgbf[valid][k].astype(np.float64)))
+            return phrases, embs, out
+        if keep is not None:
             clouds = _compact(clouds, keep)
         return phrases, embs, clouds
 
