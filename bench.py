@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--arena-gb", type=float, default=24.0)
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--lanes", type=int, default=0, help="(experiment) N concurrent whole-batch lanes instead of the two-stage pipeline")
     ap.add_argument("--sequential", action="store_true", help="run the steps back to back instead of pipelined")
     ap.add_argument("--profile-kernel", default="", help="(internal) name of the kernel the roofline is reported for")
     args = ap.parse_args()
@@ -202,7 +203,8 @@ def main():
         for i in range(args.warmup):
             run_step(eng, batches[i], args)
     else:
-        for _ in eng.localise_stream(stream_items(0, args.warmup), **kw):
+        for _ in (eng.localise_concurrent(stream_items(0, args.warmup), workers=args.lanes, worker_arena_bytes=12 << 30, **kw) if args.lanes
+                  else eng.localise_stream(stream_items(0, args.warmup), **kw)):
             pass
     barrier()
     from ibloc_amd import prof
@@ -216,7 +218,9 @@ def main():
     if args.sequential:
         step_results = (run_step(eng, batches[args.warmup + i], args, timings=timings) for i in range(args.steps))
     else:
-        step_results = eng.localise_stream(stream_items(args.warmup, args.warmup + args.steps), **kw)
+        items = stream_items(args.warmup, args.warmup + args.steps)
+        step_results = eng.localise_concurrent(items, workers=args.lanes, worker_arena_bytes=12 << 30, **kw) if args.lanes \
+            else eng.localise_stream(items, **kw)
     for i, res in enumerate(step_results):
         b = batches[args.warmup + i]
         for f, r in enumerate(res):
@@ -271,7 +275,7 @@ def main():
             "config": {"workload": f"{'C2' if args.memory == 1000 else 'T' if args.memory == 10000 else 'custom'}: {args.model} crops 224^2 "
                        f"(Q={args.q}), {args.memory}-instance memory (E={args.views}), FPFH+RANSAC+coloured ICP on {args.points}-pt clouds, "
                        "whole-memory evaluate", "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
-                       "points_per_object": args.points, "encoder": args.model, "parallelism": f"frames-dp{world_size}"},
+                       "points_per_object": args.points, "parallelism": f"frames-dp{world_size}"},
             # `roofline`: HIP events around every GEMM launch of the timed region.  With pipelined steps the embed stream shares the
             # device with the registration kernels of the previous step, so a launch's duration there is not the kernel's own
             # speed; `roofline_isolated` is the same measurement over the launches of one extra step run alone afterwards.

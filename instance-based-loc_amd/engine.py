@@ -64,6 +64,14 @@ class FrameResult:
     best: int = -1
 
 
+@dataclass
+class _Lane:
+    ctx: RegContext                       # scratch arena of this lane's registration calls
+    pool: ThreadPoolExecutor              # its detections'-features worker
+    lane: int                             # encoder workspace index
+    stream: "torch.cuda.Stream"
+
+
 class LocaliseEngine:
     def __init__(self, memory: MemoryShard, encoder=None, assign_threads=0):
         self.memory = memory
@@ -73,18 +81,21 @@ class LocaliseEngine:
         self.reuse_features = True      # False: every assignment recomputes its features (same results, the reference's schedule)
         self._pool = ThreadPoolExecutor(max_workers=1)
         self._pool_a = None             # stage-A worker of localise_stream
+        self._pool_w = None             # lane threads of localise_concurrent
+        self._lanes = []
 
-    def _det_features(self, clean, voxel_size):
-        torch.cuda.set_device(clean.pts4.device)          # worker thread: the current device is per thread
-        return instance_features_batch(self.ctx, clean, voxel_size)
+    def _det_features(self, clean, voxel_size, ctx, stream):
+        torch.cuda.set_device(clean.pts4.device)          # worker thread: the current device and stream are per thread
+        with torch.cuda.stream(stream):
+            return instance_features_batch(ctx, clean, voxel_size)
 
-    def _embed_match(self, crops, det_emb, tick=lambda name: None, to_host=True):
+    def _embed_match(self, crops, det_emb, tick=lambda name: None, to_host=True, lane=0):
         """Stage A: embed + match on the current stream -> fp16 similarity rows (one row per detection, M + 1 columns)."""
         mem = self.memory
         if det_emb is None:
             if self.encoder is None:
                 raise ValueError("no encoder: pass det_emb")
-            det_emb = self.encoder.embed(crops)
+            det_emb = self.encoder.embed(crops, lane=lane)
         else:
             det_emb = torch.as_tensor(det_emb, dtype=torch.float32, device=mem.device).contiguous()
         tick("embed")
@@ -93,6 +104,51 @@ class LocaliseEngine:
         _, aug = match.closest_similarity(detn, mem.mem_emb, mem.emb_offsets, want_sims=False, want_aug=True)   # :933-936, sim_volume :13-18
         tick("match")
         return aug.cpu().numpy() if to_host else aug
+
+    def localise_concurrent(self, batches, workers=2, worker_arena_bytes=8 << 30, **kw):
+        """`localise_batch` for a sequence of frame batches (dicts like `localise_stream` takes) on `workers` concurrent lanes: every
+        lane is a host thread with its own HIP stream, registration scratch arena and encoder workspace, and runs whole batches
+        start to end, so the host phases and launch gaps of one batch are filled by the kernels of the others.  The memory (its
+        embeddings, clouds, resident instance features and spatial hash) is shared read-only.  Results are those of
+        `localise_batch`, yielded in order."""
+        import queue
+        from collections import deque
+        dev = self.memory.mem_emb.device
+        if self.reuse_features:                              # build the resident memory features before the lanes start
+            self.memory.features(kw.get("fpfh_voxel_size", 0.05), kw.get("fpfh_local_dist_factor", 0.4))
+        while len(self._lanes) < workers:
+            k = len(self._lanes)
+            self._lanes.append(_Lane(RegContext(worker_arena_bytes), ThreadPoolExecutor(max_workers=1), k, torch.cuda.Stream(device=dev)))
+        free = queue.Queue()
+        cur = torch.cuda.current_stream(dev)
+        for lane in self._lanes[:workers]:
+            lane.stream.wait_stream(cur)                     # inputs (crops, clouds, memory) were produced on the caller's stream
+            free.put(lane)
+
+        def run(b):
+            lane = free.get()
+            try:
+                torch.cuda.set_device(dev)
+                args = dict(kw)
+                for k in ("seed", "job_id_base"):
+                    if k in b:
+                        args[k] = b[k]
+                with torch.cuda.stream(lane.stream):
+                    res = self.localise_batch(b["det"], b["q_per_frame"], crops=b.get("crops"), det_emb=b.get("det_emb"), _slot=lane, **args)
+                    lane.stream.synchronize()
+                return res
+            finally:
+                free.put(lane)
+
+        if self._pool_w is None or self._pool_w._max_workers < workers:
+            self._pool_w = ThreadPoolExecutor(max_workers=workers)
+        pending = deque()
+        for b in batches:
+            pending.append(self._pool_w.submit(run, b))
+            if len(pending) > workers:                       # keep the lanes fed, bound what is in flight
+                yield pending.popleft().result()
+        while pending:
+            yield pending.popleft().result()
 
     def localise_stream(self, batches, **kw):
         """Pipelined form of `localise_batch` for a sequence of frame batches (dicts with det, q_per_frame and crops or det_emb,
@@ -130,11 +186,12 @@ class LocaliseEngine:
     def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
                        fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, outlier_radius=0.05, outlier_nb_points=8,
                        seed=0, job_id_base=0, ransac_max_iter=4000000, num_per_length=4, eval_threshold=None, timings=None,
-                       aug_h=None):
+                       aug_h=None, _slot=None):
         """det: detected clouds of all frames (segments in frame order, <= 7 per frame); crops: uint8 tensor
         (sum Q, H, W, 3) or list of arrays, or det_emb: (sum Q, D) precomputed embeddings (or aug_h: the host similarity rows
         stage A of `localise_stream` produced)."""
         mem = self.memory
+        ctx, pool, lane = (self.ctx, self._pool, 0) if _slot is None else (_slot.ctx, _slot.pool, _slot.lane)
         q_per_frame = np.asarray(q_per_frame, dtype=np.int32)
         F = len(q_per_frame)
         row0 = np.concatenate([[0], np.cumsum(q_per_frame)]).astype(np.int64)
@@ -149,9 +206,9 @@ class LocaliseEngine:
 
         tick("start")
         # ---- embed + match (GPU) -------------------------------------------------------------------
-        aug = self._embed_match(crops, det_emb, tick, to_host=False) if aug_h is None else None
+        aug = self._embed_match(crops, det_emb, tick, to_host=False, lane=lane) if aug_h is None else None
         # ---- clean the detected clouds (:992-998) ---------------------------------------------------
-        keep = radius_outlier_batch(self.ctx, det, outlier_radius, outlier_nb_points)
+        keep = radius_outlier_batch(ctx, det, outlier_radius, outlier_nb_points)
         keepb = keep.bool()
         csum = torch.cumsum(keep.to(torch.int32), 0)
         csum0 = torch.cat([torch.zeros(1, dtype=torch.int32, device=csum.device), csum])
@@ -178,7 +235,7 @@ class LocaliseEngine:
         # cleaned clouds, so the GPU computes them while the host cores run the assignment search (both calls release the GIL).
         det_feat_job = None
         if self.reuse_features:
-            det_feat_job = self._pool.submit(self._det_features, clean, fpfh_voxel_size)
+            det_feat_job = pool.submit(self._det_features, clean, fpfh_voxel_size, ctx, torch.cuda.current_stream())
         assns = assign_batch(aug_f, q_emb, num_per_length, self.assign_threads)
         det_feat = det_feat_job.result() if det_feat_job is not None else None
         tick("assign")
@@ -195,7 +252,7 @@ class LocaliseEngine:
         J = len(job_frame)
         # instance features: the memory's are resident (built on first use), the detections' were computed above
         mem_feat = mem.features(fpfh_voxel_size, fpfh_local_dist_factor) if self.reuse_features else None
-        reg = register_batch(self.ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
+        reg = register_batch(ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
                              fpfh_local_dist_factor, seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter,
                              have_colors=True, center=True, det_features=det_feat, mem_features=mem_feat)
         if timings is not None:
@@ -211,7 +268,7 @@ class LocaliseEngine:
         jb = [int(new_off_h[row0[f]]) for f in job_frame]
         je = [int(new_off_h[row0[f + 1]]) for f in job_frame]
         thr = eval_threshold if eval_threshold is not None else mem.eval_threshold
-        full_rmse, full_fit = evaluate_batch(self.ctx, mem.grid, clean.pts4, jb, je, G, thr)     # :1104
+        full_rmse, full_fit = evaluate_batch(ctx, mem.grid, clean.pts4, jb, je, G, thr)     # :1104
         tick("evaluate")
         # ---- selection + pose (:1111-1131) -----------------------------------------------------------
         j = 0

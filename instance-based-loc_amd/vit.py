@@ -275,13 +275,12 @@ class VitEncoder:
         ws = self._ws_lanes.get(lane)
         if ws is None or ws.numel() < ws_bytes:
             ws = self._ws_lanes[lane] = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
-        self._ws = ws
         if self.cfg.out_all_tokens:
             out = torch.empty((batch, self.cfg.n_tokens, self.cfg.dim), dtype=torch.float32, device=self.device)
         else:
             out = torch.empty((batch, self.cfg.out_dim), dtype=torch.float32, device=self.device)
         st = _lib.lib.ibl_vit_forward(C.byref(self.desc), C.byref(self.W), patches.data_ptr(), batch, out.data_ptr(),
-                                      self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "ibl_vit_forward")
         return out
 
@@ -298,7 +297,7 @@ class VitEncoder:
         out[:, :cfg.patch_k] = t.to(torch.bfloat16)
         return out
 
-    def embed(self, crops, max_batch=512, streams=1, min_split=128) -> torch.Tensor:
+    def embed(self, crops, max_batch=512, streams=1, min_split=128, lane=0) -> torch.Tensor:
         """crops -> (N, out_dim) fp32 device tensor (un-normalised CLS embedding, as the reference returns).
 
         streams > 1: a batch of >= min_split crops is embedded as that many micro-batches on their own HIP streams.  The layers of
@@ -324,7 +323,7 @@ class VitEncoder:
             return torch.cat(outs, dim=0)
         outs = []
         for i in range(0, n, max_batch):
-            outs.append(self.forward_patches(self.preprocess(crops[i:i + max_batch])))
+            outs.append(self.forward_patches(self.preprocess(crops[i:i + max_batch]), lane=lane))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
 

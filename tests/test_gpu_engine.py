@@ -189,4 +189,12 @@ def test_pipelined_stream_equals_batch_by_batch():
             assert a.assignments == b.assignments and a.best == b.best and len(a.assignments) > 0
             assert np.array_equal(a.pose, b.pose) and np.array_equal(a.pose_corrected, b.pose_corrected)
     assert list(eng.localise_stream([], **kw)) == []
+    # concurrent lanes (own stream / scratch arena / encoder workspace each): same results again, in order
+    for workers in (2, 3):
+        lanes = list(eng.localise_concurrent(batches, workers=workers, worker_arena_bytes=2 << 30, **kw))
+        assert len(lanes) == 4
+        for ra, rb in zip(one, lanes):
+            for a, b in zip(ra, rb):
+                assert a.assignments == b.assignments and a.best == b.best
+                assert np.array_equal(a.pose, b.pose) and np.array_equal(a.pose_corrected, b.pose_corrected)
     ctx.close()
