@@ -184,6 +184,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
     // between those groups: a piece blocks its wave's issue port for ~100 cycles, and eight of them back to back at the top
     // of the step (right after the barrier, in every wave at once) left the MFMA pipe idle for a third of the step.
     constexpr int KS = BK / 32, NG = KS * MI, NP = GA + GW;
+#ifndef IBL_GEMM_NGI_DIV
+#define IBL_GEMM_NGI_DIV 2
+#endif
+    constexpr int NGI = NG / IBL_GEMM_NGI_DIV;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
@@ -206,7 +210,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
                 const int g = ks * MI + i;
 #pragma unroll
-                for (int pc = g * NP / NG; pc < (g + 1) * NP / NG; ++pc) {
+                // pieces are issued over the first half of the step's groups: one issued in the last groups has not landed at the
+                // vmcnt(0) that closes the step (744 -> 760 TFLOP/s per layer; the first quarter only: 753)
+                for (int pc = (g < NGI ? g * NP / NGI : NP); pc < (g < NGI ? (g + 1) * NP / NGI : NP); ++pc) {
                     if (more) {
                         if (pc < GA)
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[pc] + ko),
