@@ -44,33 +44,81 @@ int ibl_launch_bbox(const float4* pts, const int* seg_off_dev, int n_seg, float*
     return IBL_OK;
 }
 
-// single block: per-segment grid dimensions and the cell-base prefix (S is small)
-__global__ void ibl_grid_dims_kernel(const float* __restrict__ bbox, int n_seg, float cell, long long max_cells,
-                                     SegGrid* __restrict__ seg, int* __restrict__ total_cells, int* __restrict__ status) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    long long base = 0;
-    for (int s = 0; s < n_seg; ++s) {
-        const float* b = bbox + s * 6;
-        const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
-        float c = cell;
-        const float emax = fmaxf(ex, fmaxf(ey, ez));
-        if (emax / 128.0f > c) c = emax / 128.0f;     // bound the table: at most ~129 cells per axis
+// single block of 256 threads: per-segment grid dimensions and the cell-base prefix, 256 segments per round (a serial loop over
+// a few thousand job sides cost ~60 us per grid, several grids per batch)
+__device__ __forceinline__ SegGrid seg_dims(const float* __restrict__ b, float cell) {
+    const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+    float c = cell;
+    const float emax = fmaxf(ex, fmaxf(ey, ez));
+    if (emax / 128.0f > c) c = emax / 128.0f;     // bound the table: at most ~129 cells per axis
+    SegGrid g;
+    g.minx = b[0]; g.miny = b[1]; g.minz = b[2];
+    g.inv = 1.0f / c;
+    g.nx = (int)floorf(ex * g.inv) + 1;
+    g.ny = (int)floorf(ey * g.inv) + 1;
+    g.nz = (int)floorf(ez * g.inv) + 1;
+    g.cell_base = 0;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void ibl_grid_dims_kernel(const float* __restrict__ bbox, int n_seg, float cell, long long max_cells,
+                                                            SegGrid* __restrict__ seg, int* __restrict__ total_cells, int* __restrict__ status) {
+    __shared__ long long wave_sum[4];
+    __shared__ long long carry;
+    __shared__ int overflow_at;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry = 0; overflow_at = -1; }
+    __syncthreads();
+    for (int base = 0; base < n_seg; base += 256) {
+        const int s = base + tid;
         SegGrid g;
-        g.minx = b[0]; g.miny = b[1]; g.minz = b[2];
-        g.inv = 1.0f / c;
-        g.nx = (int)floorf(ex * g.inv) + 1;
-        g.ny = (int)floorf(ey * g.inv) + 1;
-        g.nz = (int)floorf(ez * g.inv) + 1;
-        g.cell_base = (int)base;
-        base += (long long)g.nx * g.ny * g.nz;
-        if (base > max_cells) {
-            atomicOr(status, IBL_ST_GRID_OVERFLOW);
-            g.nx = g.ny = g.nz = 1;                    // keep later kernels in bounds
-            base = g.cell_base + 1;
+        long long cells = 0;
+        if (s < n_seg) {
+            g = seg_dims(bbox + s * 6, cell);
+            cells = (long long)g.nx * g.ny * g.nz;
         }
-        seg[s] = g;
+        long long incl = cells;                      // inclusive scan inside the wave, then across the four waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        long long before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_sum[w];
+        const long long excl = before + incl - cells;
+        if (s < n_seg) {
+            if (excl + cells > max_cells) atomicMin(&overflow_at, s);     // handled serially below (error path)
+            g.cell_base = (int)excl;
+            seg[s] = g;
+        }
+        __syncthreads();
+        if (tid == 0) carry += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+        if (overflow_at >= 0) break;
     }
-    *total_cells = (int)base;
+    if (overflow_at >= 0) {
+        // budget exceeded: from the first offending segment on, the serial rule (that segment and every later one that does not
+        // fit collapse to one cell; the status bit tells the host)
+        if (tid == 0) {
+            long long base = seg[overflow_at].cell_base;
+            for (int s = overflow_at; s < n_seg; ++s) {
+                SegGrid g = seg_dims(bbox + s * 6, cell);
+                g.cell_base = (int)base;
+                base += (long long)g.nx * g.ny * g.nz;
+                if (base > max_cells) {
+                    atomicOr(status, IBL_ST_GRID_OVERFLOW);
+                    g.nx = g.ny = g.nz = 1;                    // keep later kernels in bounds
+                    base = g.cell_base + 1;
+                }
+                seg[s] = g;
+            }
+            *total_cells = (int)base;
+        }
+        return;
+    }
+    if (tid == 0) *total_cells = (int)carry;
 }
 
 __global__ __launch_bounds__(256) void ibl_cell_id_kernel(const float4* __restrict__ pts, const int* __restrict__ seg_off, int n_seg,
@@ -108,7 +156,7 @@ int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off
     if (n_seg == 0) return IBL_OK;
     hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox);
     IBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ibl_grid_dims_kernel, dim3(1), dim3(64), 0, s, bbox, n_seg, cell, (long long)max_cells, seg, total,
+    hipLaunchKernelGGL(ibl_grid_dims_kernel, dim3(1), dim3(256), 0, s, bbox, n_seg, cell, (long long)max_cells, seg, total,
                        ctx->d_status);
     IBL_LAUNCH_CHECK();
     int h_total = 0;
