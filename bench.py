@@ -45,6 +45,18 @@ def smooth_image(rng, size=224):
     return img
 
 
+def host_cores():
+    """host cores this process may use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes give one GPU a 16-core share)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def build_workload(args, rank, device):
     import torch
     from ibloc_amd import vit as V
@@ -76,7 +88,7 @@ def build_workload(args, rank, device):
     ctx = RegContext(int(args.arena_gb * (1 << 30)))
     mem = MemoryShard(ctx, list(mem_emb), world.points, colors=world.colors, device=device)
     # host cores are shared by the ranks of the node: the assignment search takes its share, at most 16 threads
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     eng = LocaliseEngine(mem, enc, assign_threads=max(1, min(16, cores // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))
     # query batches (distinct per step and per rank), device resident
     batches = []
@@ -119,7 +131,7 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
     from oracle import vit_oracle as vo
 
     import torch
-    threads = min(16, os.cpu_count() or 1)          # the GPU box gives one GPU's share of 16 host cores
+    threads = min(16, host_cores())                 # the GPU box gives one GPU's share of 16 host cores
     torch.set_num_threads(threads)
     from oracle.clib import lib as olib
     olib.oracle_set_threads(threads)
