@@ -62,10 +62,12 @@ template <int BK> __device__ __forceinline__ int keyx_act(int r) { return BK == 
 template <int BK> __device__ __forceinline__ int keyx_w(int r) { return BK == 64 ? key_w(r) : ((r >> 4) & 1) << 1; }
 template <int BK> __device__ __forceinline__ int keyx_pair(int r) { return BK == 64 ? key_pair(r) : ((r >> 3) & 1) << 1; }
 
-// C[M][N] = A[M][K] * W[N][K]^T.  Block tile (WM * MI * 16) x (WN * 64), one wave per (MI * 16) x 64 sub-tile:
-//   <MI = 4, WM = 2, WN = 2>: 128 x 128, 256 threads, 64 KiB LDS (2 blocks / CU)  -- any N % 128 == 0
-//   <MI = 8, WM = 2, WN = 4>: 256 x 256, 512 threads, 128 KiB LDS (1 block / CU) -- N % 256 == 0; halves the operand
+// C[M][N] = A[M][K] * W[N][K]^T.  Block tile (WM * MI * 16) x (WN * 64) x BK, one wave per (MI * 16) x 64 sub-tile, two LDS stages:
+//   <MI = 4, WM = 2, WN = 2, BK = 64>: 128 x 128, 256 threads, 64 KiB LDS (2 blocks / CU)  -- any N % 128 == 0
+//   <MI = 8, WM = 2, WN = 4, BK = 64>: 256 x 256, 512 threads, 128 KiB LDS (1 block / CU) -- N % 256 == 0; halves the operand
 //                             traffic per FLOP (the 128 x 128 form saturates the L2 path at ~7 TB/s)
+//   <MI = 8, WM = 2, WN = 2, BK = 32>: 256 x 128, 256 threads, 48 KiB LDS (2 blocks / CU); measured slower than 256 x 256 on
+//                             every ViT-B shape (launch_gemm, IBL_GEMM_CFG=2)
 // The MFMA computes the TRANSPOSED tile (W is the A operand, the activations the B operand) and MFMA row 4*fg + r of
 // n-tile j is mapped to weight row 16*fg + 4*j + r, so that every lane ends up with 16 CONSECUTIVE output columns of one
 // output row: the epilogue is 16-byte vector stores.  Operand tiles are staged with direct-to-LDS loads
