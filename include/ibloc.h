@@ -244,6 +244,12 @@ enum { IBL_DEPTH_F32 = 0, IBL_DEPTH_U16 = 1, IBL_DEPTH_F64 = 2 };
 int ibl_unproject_masks(ibl_reg_ctx* ctx, const void* depth, int depth_type, const uint8_t* rgb, const uint8_t* masks, int n_masks,
                         int H, int W, double fx, double fy, double depth_factor, float* pts4, int64_t capacity,
                         int32_t* seg_off_dev, int32_t* seg_off_host, void* stream);
+/* Same, and additionally the clouds as the reference's Open3D containers hold them for the memory build (process_image,
+ * object_memory/object_memory.py:163-256): pts3_f64 / colors3_f64 [dev] capacity x 3 doubles or NULL = the numpy values (float32
+ * or float64 by the promotion rule above; colours = float32 rgb / 255) widened to double, same order as pts4. */
+int ibl_unproject_masks_f64(ibl_reg_ctx* ctx, const void* depth, int depth_type, const uint8_t* rgb, const uint8_t* masks, int n_masks,
+                            int H, int W, double fx, double fy, double depth_factor, float* pts4, double* pts3_f64, double* colors3_f64,
+                            int64_t capacity, int32_t* seg_off_dev, int32_t* seg_off_host, void* stream);
 
 /* keep[i] = 1 iff the point has more than nb_points points (itself included) within `radius` of its
  * own cloud.  Replaces PointCloud.remove_radius_outlier (object_memory/object_memory.py:994-995,

@@ -56,6 +56,8 @@ _SIGS = {
                                       vp, vp, vp]),
     "ibl_voxel_downsample_batch": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_double, vp, vp, vp, vp, vp]),
     "ibl_dbscan_batch": (C.c_int, [vp, vp, vp, C.c_int32, C.c_double, C.c_int32, vp, vp, vp]),
+    "ibl_unproject_masks_f64": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, vp, vp, vp,
+                                          C.c_int64, vp, vp, vp]),
     "ibl_radius_outlier_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp]),
     "ibl_normals_fpfh_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp]),
     "ibl_register_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,

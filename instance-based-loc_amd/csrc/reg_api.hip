@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void ibl_unproject_write_kernel(const void* __
                                                                   const int* __restrict__ flags, const int* __restrict__ pos, int64_t HW, int W,
                                                                   int64_t total, const float* __restrict__ hx, const float* __restrict__ vy,
                                                                   double fx, double fy, double depth_factor, int64_t capacity,
-                                                                  float4* __restrict__ out) {
+                                                                  float4* __restrict__ out, double* __restrict__ out_pts64, double* __restrict__ out_cols64) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total || !flags[t]) return;
     const int o = pos[t];
@@ -285,6 +285,10 @@ __global__ __launch_bounds__(256) void ibl_unproject_write_kernel(const void* __
     const float r = (float)rgb[3 * p] / 255.0f, g = (float)rgb[3 * p + 1] / 255.0f, b = (float)rgb[3 * p + 2] / 255.0f;
     const double inten = ((double)r + (double)g + (double)b) / 3.0;
     out[o] = make_float4((float)x, (float)y, (float)z, (float)inten);
+    if (out_pts64) {            // what Open3D's Vector3dVector holds: the numpy values (float32 or float64) widened to double
+        out_pts64[3 * (int64_t)o] = x; out_pts64[3 * (int64_t)o + 1] = y; out_pts64[3 * (int64_t)o + 2] = is_u16 == 0 ? (double)(float)z : z;
+    }
+    if (out_cols64) { out_cols64[3 * (int64_t)o] = (double)r; out_cols64[3 * (int64_t)o + 1] = (double)g; out_cols64[3 * (int64_t)o + 2] = (double)b; }
 }
 
 // np.linspace(start, stop, num, dtype=float32): float64 `i * step + start`, last element = stop, rounded to float32
@@ -299,9 +303,20 @@ static void linspace_f32(double start, double stop, int num, std::vector<float>&
     out[num - 1] = (float)stop;
 }
 
+extern "C" int ibl_unproject_masks_f64(ibl_reg_ctx* ctx, const void* depth, int depth_type, const uint8_t* rgb, const uint8_t* masks,
+                                       int n_masks, int H, int W, double fx, double fy, double depth_factor, float* pts4, double* pts3_f64,
+                                       double* colors3_f64, int64_t capacity, int32_t* seg_off_dev, int32_t* seg_off_host, void* stream);
+
 extern "C" int ibl_unproject_masks(ibl_reg_ctx* ctx, const void* depth, int depth_type, const uint8_t* rgb, const uint8_t* masks,
                                    int n_masks, int H, int W, double fx, double fy, double depth_factor, float* pts4, int64_t capacity,
                                    int32_t* seg_off_dev, int32_t* seg_off_host, void* stream) {
+    return ibl_unproject_masks_f64(ctx, depth, depth_type, rgb, masks, n_masks, H, W, fx, fy, depth_factor, pts4, nullptr, nullptr, capacity,
+                                   seg_off_dev, seg_off_host, stream);
+}
+
+extern "C" int ibl_unproject_masks_f64(ibl_reg_ctx* ctx, const void* depth, int depth_type, const uint8_t* rgb, const uint8_t* masks,
+                                       int n_masks, int H, int W, double fx, double fy, double depth_factor, float* pts4, double* pts3_f64,
+                                       double* colors3_f64, int64_t capacity, int32_t* seg_off_dev, int32_t* seg_off_host, void* stream) {
     if (!ctx || !seg_off_dev || !seg_off_host || n_masks < 0 || (n_masks > 0 && (!depth || !rgb || !masks || !pts4)) || H <= 0 || W <= 0 || fx == 0 || fy == 0 ||
         depth_factor == 0 || capacity < 0 || depth_type < 0 || depth_type > 2)
         return ibl_set_error(IBL_ERR_ARG, "ibl_unproject_masks: bad argument");
@@ -339,7 +354,7 @@ extern "C" int ibl_unproject_masks(ibl_reg_ctx* ctx, const void* depth, int dept
     for (int m = 0; m <= n_masks; ++m) seg_off_host[m] = off[m];
     IBL_HIP_CHECK(hipMemcpyAsync(seg_off_dev, seg_off_host, sizeof(int) * (n_masks + 1), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(ibl_unproject_write_kernel, dim3(nb), dim3(256), 0, s, depth, depth_type, rgb, flags, pos, HW, W, total, d_hx, d_vy, fx, fy,
-                       depth_factor, capacity, reinterpret_cast<float4*>(pts4));
+                       depth_factor, capacity, reinterpret_cast<float4*>(pts4), pts3_f64, colors3_f64);
     IBL_LAUNCH_CHECK();
     IBL_HIP_CHECK(hipStreamSynchronize(s));
     return IBL_OK;

@@ -331,23 +331,22 @@ class ObjectMemory():
         else:
             d_t = torch.from_numpy(d_np.astype(np.float64)).to(dev)
         clouds = unproject_masks(self._ctx, d_t, torch.from_numpy(np.array(rgb, dtype=np.uint8)).to(dev), (m_t != 0).to(dev),
-                                 self.camera_focal_lenth_x, self.camera_focal_lenth_y, depth_factor)
+                                 self.camera_focal_lenth_x, self.camera_focal_lenth_y, depth_factor, want_f64=for_build)
+        if for_build:
+            clouds, p64, c64 = clouds
         keep = None
         if outlier_removal_config is not None and clouds.n > 0:
             keep = radius_outlier_batch(self._ctx, clouds, outlier_removal_config["radius"], outlier_removal_config["radius_nb_points"])
         if for_build:
-            # memory build: (points, colours) per object on the host, colours = float32 rgb / 255 of the surviving pixels
-            # (utils/depth_utils.py:73-80); coordinates are those of the HBM layout (float32)
-            pts = clouds.pts4[:, :3].double().cpu().numpy()
+            # memory build: (points, colours) per object on the host with the values of the reference's Open3D clouds (float32 or
+            # float64 products by numpy's promotion, colours = float32 rgb / 255; utils/depth_utils.py:63-80)
             kh = keep.bool().cpu().numpy() if keep is not None else np.ones(clouds.n, dtype=bool)
-            rgbf = (np.asarray(rgb).astype(np.float32) / 255.0).reshape(-1, 3)
-            m_h = (m_t != 0).reshape(len(masks), -1).numpy() if len(masks) else np.zeros((0, d_np.size), dtype=bool)
-            out = []
+            pts, cols = p64.cpu().numpy(), c64.cpu().numpy()
             off = clouds.seg_off_host
+            out = []
             for i in range(len(masks)):
-                valid = m_h[i] & (d_np.reshape(-1) != 0)
                 k = kh[off[i]:off[i + 1]]
-                out.append((pts[off[i]:off[i + 1]][k], rgbf[valid][k].astype(np.float64)))
+                out.append((pts[off[i]:off[i + 1]][k], cols[off[i]:off[i + 1]][k]))
             return phrases, embs, out
         if keep is not None:
             clouds = _compact(clouds, keep)

@@ -78,10 +78,11 @@ class CloudBatch:
 
 
 def unproject_masks(ctx: RegContext, depth: torch.Tensor, rgb: torch.Tensor, masks: torch.Tensor, fx: float, fy: float,
-                    depth_factor: float = 1.0) -> CloudBatch:
+                    depth_factor: float = 1.0, want_f64: bool = False):
     """One coloured cloud per instance mask from a depth image (get_mask_coloured_pointclouds_from_depth,
     utils/depth_utils.py:176-206, before its outlier step).  depth (H, W) float32, float64 or uint16 (int16 storage is read as uint16), rgb (H, W, 3)
-    uint8, masks (n, H, W) bool / uint8 -- device tensors.  Returns the clouds as a CloudBatch (x, y, z, intensity)."""
+    uint8, masks (n, H, W) bool / uint8 -- device tensors.  Returns the clouds as a CloudBatch (x, y, z, intensity); with want_f64 also
+    (points, colours) as (N, 3) float64 device tensors holding exactly the values of the reference's Open3D clouds (memory build)."""
     dev = depth.device
     assert depth.is_cuda and rgb.is_cuda and masks.is_cuda and depth.dim() == 2
     H, W = depth.shape
@@ -99,10 +100,16 @@ def unproject_masks(ctx: RegContext, depth: torch.Tensor, rgb: torch.Tensor, mas
     pts4 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
     off_dev = torch.zeros(n + 1, dtype=torch.int32, device=dev)
     off_host = np.zeros(n + 1, dtype=np.int32)
-    st = _lib.lib.ibl_unproject_masks(ctx.handle, d.data_ptr(), is_u16, rgb.data_ptr(), m.data_ptr(), n, H, W, float(fx), float(fy),
-                                      float(depth_factor), pts4.data_ptr(), cap, off_dev.data_ptr(), off_host.ctypes.data, _stream())
-    _lib.check(st, "ibl_unproject_masks")
-    return CloudBatch(pts4[:int(off_host[-1])].contiguous() if off_host[-1] != cap or cap == 0 else pts4, off_host)
+    p64 = torch.empty((max(cap, 1), 3), dtype=torch.float64, device=dev) if want_f64 else None
+    c64 = torch.empty((max(cap, 1), 3), dtype=torch.float64, device=dev) if want_f64 else None
+    st = _lib.lib.ibl_unproject_masks_f64(ctx.handle, d.data_ptr(), is_u16, rgb.data_ptr(), m.data_ptr(), n, H, W, float(fx), float(fy),
+                                          float(depth_factor), pts4.data_ptr(), p64.data_ptr() if want_f64 else None,
+                                          c64.data_ptr() if want_f64 else None, cap, off_dev.data_ptr(), off_host.ctypes.data, _stream())
+    _lib.check(st, "ibl_unproject_masks_f64")
+    batch = CloudBatch(pts4[:int(off_host[-1])].contiguous() if off_host[-1] != cap or cap == 0 else pts4, off_host)
+    if want_f64:
+        return batch, p64[:int(off_host[-1])], c64[:int(off_host[-1])]
+    return batch
 
 
 def radius_outlier_batch(ctx: RegContext, batch: CloudBatch, radius: float, nb_points: int) -> torch.Tensor:

@@ -196,4 +196,17 @@ def test_process_image_through_stub_finder(tmp_path):
         assert np.array_equal(obj.embeddings[0], embs[mi])
     with pytest.raises(NotImplementedError):
         mem.process_image("a", "b", pose, False, will_cluster_later=False)
+    # a 16-bit depth image with the Kinect factor: the reference's clouds are float64 products, and so are the memory's
+    d16 = np.round(depth * 5000.0).astype(np.uint16)
+    np.save(tmp_path / "depth16.npy", d16)
+    calls.clear()
+    mem.memory, mem.floors = [], None
+    mem.process_image(str(tmp_path / "rgb.png"), str(tmp_path / "depth16.npy"), pose.copy(), consider_floor=False,
+                      outlier_removal_config=cfg, min_points=200, depth_factor=5000.)
+    for obj, mi in ((mem.memory[0], 0), (mem.floors, 1)):
+        pts, cols = do.coloured_pointcloud_from_depth((d16 / 5000.) * masks[mi, 0].numpy(), rgb, 90.0, 85.0)
+        assert pts.dtype == np.float64
+        keep = ro.radius_outlier(pts.astype(np.float32), cfg["radius"], cfg["radius_nb_points"])
+        assert np.array_equal(obj.pointcloud.points, (R @ pts[keep].T).T + pose[:3])
+        assert np.array_equal(obj.pointcloud.colors, cols[keep].astype(np.float64))
     mem._ctx.close()
