@@ -103,7 +103,7 @@ extern "C" int ibl_gemm_stamps_read(long long* dst, int n) {
 #define GEMM_STAMP(k)
 #endif
 
-template <int EPI, int MI, int WM, int WN, int BK, int OCC>
+template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
                                                                   int64_t ldw, int M, int N, int K, GemmEpi epi) {
     constexpr int BM = WM * MI * 16, BN = WN * 64, NW = WM * WN;
@@ -170,8 +170,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
 
     const int nk = K / BK;
     GEMM_STAMP(0);
-    GEMM_GLDS(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int NP = GA + GW;
+    // NS LDS stages: the loads of K steps 0 .. NS - 2 are in flight before the loop, step kt issues those of step kt + NS - 1, and the
+    // wait that closes a step lets the (NS - 2) youngest stages stay in flight (vmcnt counts LDS-DMA pieces in issue order)
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) GEMM_GLDS(st, st);
+    if (NS == 2 || nk < NS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * NP) : "memory");
     __syncthreads();
     GEMM_STAMP(1);
     const int fr = lane & 15, fg = lane >> 4;
@@ -185,16 +191,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
     // One K step = 2 * MI groups of 4 MFMAs.  The GA + GW direct-to-LDS pieces of the NEXT tile are issued one at a time
     // between those groups: a piece blocks its wave's issue port for ~100 cycles, and eight of them back to back at the top
     // of the step (right after the barrier, in every wave at once) left the MFMA pipe idle for a third of the step.
-    constexpr int KS = BK / 32, NG = KS * MI, NP = GA + GW;
+    constexpr int KS = BK / 32, NG = KS * MI;
 #ifndef IBL_GEMM_NGI_DIV
 #define IBL_GEMM_NGI_DIV 2
 #endif
     constexpr int NGI = NG / IBL_GEMM_NGI_DIV;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        const int64_t ko = (int64_t)(kt + 1) * BK;
-        unsigned char* nxt = smem + (buf ^ 1) * STAGE;
+        const int buf = kt % NS;
+        const bool more = kt + NS - 1 < nk;
+        const int64_t ko = (int64_t)(kt + NS - 1) * BK;
+        unsigned char* nxt = smem + ((kt + NS - 1) % NS) * STAGE;
         const unsigned char* pa = smem + buf * STAGE;
         const unsigned char* pw = pa + A_BYTES;
 #pragma unroll
@@ -226,7 +232,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed in LDS
+        // stage kt + 1 has landed; the pieces of later steps (issued during this step and the ones before) may still be in flight
+        if (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int later = nk - 2 - kt;               // K steps after kt + 1 ...
+            if (later >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * NP) : "memory");
+            else if (NS >= 4 && later == NS - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS >= 4 ? NS - 3 : 0) * NP) : "memory");
+            else if (NS >= 5 && later == NS - 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS >= 5 ? NS - 4 : 0) * NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
     }
 #undef GEMM_GLDS
@@ -360,20 +375,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
 #endif
 }
 
-template <int EPI, int MI, int WM, int WN, int BK, int OCC>
+template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS>
 static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     const int nwg = (N / BN) * ((M + BM - 1) / BM);
-    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+    const size_t lds = NS * (size_t)(BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC>),
+        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC, NS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     void* tok;
     ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);
-    hipLaunchKernelGGL((ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC, NS>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
@@ -383,6 +398,7 @@ static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw,
 //   0  256 x 256, BK 64, 8 waves, 128 KiB LDS, 1 block / CU   (fewest operand bytes per FLOP)
 //   1  128 x 128, BK 64, 4 waves,  64 KiB LDS, 2 blocks / CU  (any N % 128 == 0, small M)
 //   2  256 x 128, BK 32, 4 waves,  48 KiB LDS, 2 blocks / CU  (the epilogue of one block overlaps the K loop of the other)
+//   3  256 x 256, BK 32, 8 waves, 4 LDS stages = 128 KiB      (loads two K steps ahead, no full drain at the step boundary)
 static int gemm_cfg_override() {
     static int v = -2;
     if (v == -2) {
@@ -400,13 +416,14 @@ static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int
         return ibl_set_error(IBL_ERR_ARG, "gemm: N (%d) must be a multiple of 128 and K (%d) of 64", N, K);
     int cfg = (N % 256 == 0 && M >= 4096) ? 0 : 1;
     const int ov = gemm_cfg_override();
-    if (ov == 1 || ov == 2 || (ov == 0 && N % 256 == 0)) cfg = ov;
+    if (ov == 1 || ov == 2 || ((ov == 0 || ov == 3) && N % 256 == 0)) cfg = ov;
 #ifdef IBL_GEMM_FORCE128
     cfg = 1;
 #endif
-    if (cfg == 0) return launch_gemm_cfg<EPI, 8, 2, 4, 64, 1>(A, lda, W, ldw, M, N, K, epi, s);
-    if (cfg == 2) return launch_gemm_cfg<EPI, 8, 2, 2, 32, 2>(A, lda, W, ldw, M, N, K, epi, s);
-    return launch_gemm_cfg<EPI, 4, 2, 2, 64, 2>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 0) return launch_gemm_cfg<EPI, 8, 2, 4, 64, 1, 2>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 2) return launch_gemm_cfg<EPI, 8, 2, 2, 32, 2, 2>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 3) return launch_gemm_cfg<EPI, 8, 2, 4, 32, 1, 4>(A, lda, W, ldw, M, N, K, epi, s);
+    return launch_gemm_cfg<EPI, 4, 2, 2, 64, 2, 2>(A, lda, W, ldw, M, N, K, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------------
