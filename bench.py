@@ -265,6 +265,9 @@ def main():
         for r in (roof, roof_iso):
             if r is not None:
                 r["traffic"] = traffic
+        if roof is not None and roof_iso is not None:
+            roof["note"] = ("pipelined steps: these launches share the device with the registration kernels of the previous step, so the "
+                            "duration of a launch is not the kernel's own speed; roofline_isolated times the same launches alone")
         cpu = None
         if args.cpu_frames > 0 and world_size == 1:       # the CPU leg is timed on rank 0 of the single-GPU run only
             v, cdt, threads = cpu_baseline(args, world, mem_emb, batches[args.warmup], args.cpu_frames)
