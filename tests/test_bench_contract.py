@@ -1,0 +1,24 @@
+"""The committed bench line (profiles/r01/bench_default.json, produced by `python bench.py` on an MI355X) keeps the driver's contract."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    line = open(os.path.join(ROOT, "profiles", "r01", "bench_default.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
+                 ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and not {"model", "global_batch", "seq_len", "encoder"} & set(d["config"])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"].split(",")[0] in base["metric"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - d["config"]["frames_per_step_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
