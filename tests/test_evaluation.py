@@ -78,3 +78,11 @@ def test_report_text_matches_driver_loop(tmp_path):
     assert out.read_text() == want
     s = rep.summary()
     assert s["total"] == 43 and 0 < s["successes"] < 43
+
+
+def test_floor_phrase_check_matches_reference_vectors():
+    from ibloc_amd.object_memory.object_finder_phrases import check_if_floor
+    cases = json.load(open(GOLD))["check_if_floor"]
+    assert len(cases) == 12 and any(c["is_floor"] for c in cases) and not all(c["is_floor"] for c in cases)
+    for c in cases:
+        assert check_if_floor(c["names"]) == c["is_floor"], c

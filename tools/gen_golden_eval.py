@@ -27,6 +27,13 @@ for i in range(64):
         b = a + 1e-9 * rng.normal(size=4)
     cases.append({"q1": a.tolist(), "q2": b.tolist(), "product": Q.quaternion_multiply(a, b).tolist(),
                   "conjugate": Q.quaternion_conjugate(a).tolist(), "error": float(Q.quaternion_error(a, b))})
+spec = importlib.util.spec_from_file_location("ref_phrases", "/root/reference/object_memory/object_finder_phrases.py")   # pure python
+ph = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ph)
+name_lists = [["floor"], ["ground", "mat"], ["earth"], ["table"], ["floor mat"], ["wooden floor"], [], ["chair", "floor"], ["Floor"], ["ground floor"],
+              ["desk", "earth"], ["grounds"]]
+floor = [{"names": c, "is_floor": bool(ph.check_if_floor(c))} for c in name_lists]
 with open(os.path.join(ROOT, "tests", "golden", "eval_golden.json"), "w") as fh:
-    json.dump({"source": "reference utils/quaternion_ops.py QuaternionOps", "cases": cases}, fh, indent=0)
+    json.dump({"source": "reference utils/quaternion_ops.py QuaternionOps", "cases": cases, "check_if_floor": floor,
+               "check_if_floor_source": "reference object_memory/object_finder_phrases.py check_if_floor"}, fh, indent=0)
 print(len(cases), "cases")
