@@ -53,6 +53,15 @@ def test_pruned_search_matches_oracle(kind, Q, M):
         assert run(sims) == so.simvolume_assignments(sims, 4)
 
 
+@pytest.mark.parametrize("Q,M,levels", [(2, 700, 3), (2, 1200, 2), (2, 600, 0), (3, 260, 5)])
+def test_heavy_ties_beyond_the_presorted_prefix(Q, M, levels):
+    """rows quantised to a few levels (levels = 0: constant): the tie scan needs |value| prefixes far beyond the 256 entries sorted
+    up front, so the on-demand full ordering of csrc/assign.cpp runs"""
+    rng = np.random.default_rng(1000 * Q + M + levels)
+    sims = (rng.integers(0, levels + 1, size=(Q, M)) / max(levels, 1) * 0.9).astype(np.float32) if levels else np.full((Q, M), 0.5, np.float32)
+    assert run(sims) == so.simvolume_assignments(sims, 4)
+
+
 def test_batch_with_ragged_q():
     rng = np.random.default_rng(7)
     M, Qs = 45, 7
