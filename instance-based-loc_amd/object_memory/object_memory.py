@@ -206,32 +206,51 @@ class ObjectMemory():
             o._compute_means()
         self._engine = None
 
-    def recluster_via_clustering_and_IoU(self, distance_func=None, embedding_distance_threshold=0.4, eps=0.4, min_points_per_cluster=150,
-                                         IoU_threshold=0.25, iou_func=None):
-        """:562-708: IoU merge, then average-linkage clustering of the mean embeddings on the reference's rescaled
-        `1 - normalised cosine distance` matrix, then DBSCAN inside every embedding cluster (all clusters in one device call)."""
+    def _embedding_labels(self, similarity, distance_func, embedding_distance_threshold):
+        """average-linkage clustering of the mean embeddings on the reference's rescaled matrix: the pairwise cosine similarity
+        (:382-386) or cosine distance (:518-522 / :565-569), shifted and scaled to [0, 1] and flipped (`1 - x`), exactly as written"""
         from sklearn.cluster import AgglomerativeClustering
-        self._recluster_IoU(IoU_threshold, iou_func)
 
         def df(all_obj_embs, all_obj_centroids):
             normalized = all_obj_embs / np.linalg.norm(all_obj_embs, axis=1, keepdims=True)
-            return 1 - np.dot(normalized, normalized.T)
+            sims = np.dot(normalized, normalized.T)
+            return sims if similarity else 1 - sims
 
-        embs = np.array([o.mean_emb for o in self.memory])
-        cents = np.array([o.centroid for o in self.memory])
-        D = (distance_func or df)(embs, cents)
+        D = (distance_func or df)(np.array([o.mean_emb for o in self.memory]), np.array([o.centroid for o in self.memory]))
         D -= np.min(D)
         D /= np.max(D)
         D = 1 - D
         self._log("Clustering agglomeratively")
-        labels = AgglomerativeClustering(n_clusters=None, distance_threshold=embedding_distance_threshold, metric='precomputed',
-                                         linkage='average').fit(D).labels_
+        return AgglomerativeClustering(n_clusters=None, distance_threshold=embedding_distance_threshold, metric='precomputed',
+                                       linkage='average').fit(D).labels_
+
+    def recluster_via_agglomerative_clustering(self, distance_func=None, embedding_distance_threshold=0.4, distance_threshold=0.1):
+        """:379-437: merge the objects of every embedding cluster (no geometry involved)"""
+        labels = self._embedding_labels(True, distance_func, embedding_distance_threshold)
+        self._log(f"{len(set(labels))} objects clustered")
+        new_memory = [None for _ in set(labels)]
+        for lab, obj in zip(labels, self.memory):
+            new_memory[lab] = obj if new_memory[lab] is None else new_memory[lab] + obj
+        self.memory = new_memory
+        for i, o in enumerate(self.memory):
+            o.id = i
+        self._engine = None
+
+    def recluster_via_combined(self, distance_func=None, embedding_distance_threshold=0.4, eps=0.4, min_points_per_cluster=150):
+        """:443-553: embedding clusters, then DBSCAN inside every cluster (all clusters in one device call) and a merge per DBSCAN label"""
+        labels = self._embedding_labels(False, distance_func, embedding_distance_threshold)
         self._log(f"{len(set(labels))} clusters initially")
         groups = [[o for i, o in enumerate(self.memory) if labels[i] == u] for u in set(labels)]
         self.memory = [o for merged in self._dbscan_merge(groups, eps, min_points_per_cluster) for o in merged]
         for i, o in enumerate(self.memory):
             o.id = i
         self._engine = None
+
+    def recluster_via_clustering_and_IoU(self, distance_func=None, embedding_distance_threshold=0.4, eps=0.4, min_points_per_cluster=150,
+                                         IoU_threshold=0.25, iou_func=None):
+        """:562-708: `_recluster_IoU`, then the steps of `recluster_via_combined`"""
+        self._recluster_IoU(IoU_threshold, iou_func)
+        self.recluster_via_combined(distance_func, embedding_distance_threshold, eps, min_points_per_cluster)
 
     # ---- persistence: the reference's pickle layout (object_memory.py:779-846) -----------------------------
     def save_to_pkl(self, save_directory: str):

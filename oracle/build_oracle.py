@@ -193,3 +193,19 @@ def aabb_iou(p1, p2):            # utils/IoU_ops.py:9-51 on arrays
     ov = v[0] * v[1] * v[2]
     e1, e2 = a.max(axis=-1) - a.min(axis=-1), b.max(axis=-1) - b.min(axis=-1)
     return ov / (e1[0] * e1[1] * e1[2] + e2[0] * e2[1] * e2[2] - ov)
+
+
+def recluster_via_agglomerative_clustering(memory, embedding_distance_threshold):       # object_memory.py:379-437
+    from sklearn.cluster import AgglomerativeClustering
+    embs = np.array([o.mean_emb for o in memory])
+    normalized = embs / np.linalg.norm(embs, axis=1, keepdims=True)
+    D = np.dot(normalized, normalized.T)
+    D -= np.min(D)
+    D /= np.max(D)
+    D = 1 - D
+    labels = AgglomerativeClustering(n_clusters=None, distance_threshold=embedding_distance_threshold, metric='precomputed',
+                                     linkage='average').fit(D).labels_
+    new_memory = [None for _ in set(labels)]
+    for lab, o in zip(labels, memory):
+        new_memory[lab] = o if new_memory[lab] is None else new_memory[lab] + o
+    return new_memory

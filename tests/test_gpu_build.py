@@ -126,6 +126,17 @@ def test_consolidation_matches_reference_transcript():
         with pytest.raises(NotImplementedError):
             mem._recluster_IoU(0.3)                                      # the object-aligned IoU is not part of this build
         mem._ctx.close()
+    # recluster_via_agglomerative_clustering (:379-437): embedding clusters only
+    mem = ObjectMemory(device="cuda", get_embeddings_func=lambda **kw: None, log_enabled=False, arena_bytes=1 << 30)
+    want = []
+    for name, emb, p, c in _fragments(11):
+        mem.add_object(name, [emb], p, c)
+        want.append(bo.Obj(name, emb, p, c))
+    mem.recluster_via_agglomerative_clustering(embedding_distance_threshold=0.5)
+    want = bo.recluster_via_agglomerative_clustering(want, 0.5)
+    _same_memory(mem, want)
+    assert 6 <= len(mem.memory) <= 12
+    mem._ctx.close()
 
 
 def test_process_detections_and_floor_removal():
