@@ -10,7 +10,7 @@ crops and detected clouds are already resident in HBM.  Consecutive steps are pi
 --sequential runs them back to back); all work of the K timed steps happens inside the timed region.  Synthetic data and
 seeded random-init weights (no datasets / checkpoints offline).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 40 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -167,7 +167,7 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32, help="query frames per step and per GPU")
     ap.add_argument("--memory", type=int, default=1000)
