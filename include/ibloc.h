@@ -374,6 +374,15 @@ int ibl_evaluate_batch(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* d
                        const int32_t* job_end, const double* T_global, int n_jobs, double threshold, double* rmse_out,
                        double* fitness_out, void* stream);
 
+/* Same, and additionally the squared distance of every transformed detected point to its nearest memory point within `threshold`
+ * (+inf when there is none): d2_out [dev] floats, job j's points at offset sum_{i<j} (job_end[i] - job_begin[i]).  This is the
+ * per-shard half of the sharded whole-memory evaluation of SURVEY 8(e): every rank evaluates against the memory points it owns, the
+ * distances are combined with an all-reduce(MIN) (RCCL) and fitness / rmse follow from the combined array
+ * (ibloc_amd.parallel.evaluate_sharded). */
+int ibl_evaluate_points(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* det_pts4, const int32_t* job_begin,
+                        const int32_t* job_end, const double* T_global, int n_jobs, double threshold, float* d2_out, double* rmse_out,
+                        double* fitness_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ _SIGS = {
     "ibl_memgrid_build": (C.c_int, [vp, vp, C.c_int64, C.c_double, C.POINTER(vp), vp]),
     "ibl_memgrid_destroy": (C.c_int, [vp]),
     "ibl_evaluate_batch": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, vp, vp]),
+    "ibl_evaluate_points": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, vp, vp, vp]),
     "ibl_dator_head_workspace_bytes": (C.c_int64, [C.c_int]),
     "ibl_dator_head_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),
     "ibl_preprocess_depth": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),

@@ -1608,11 +1608,13 @@ extern "C" int ibl_memgrid_destroy(ibl_memgrid* g) {
 struct EvalJob {
     double T[12];
     int begin, end;      // detected point range (all cleaned detected clouds of the job's frame)
+    long long out;       // offset of this job's per-point distances (ibl_evaluate_points)
 };
 
 // grid (ICP_BPJ, J): fitness / rmse partials of evaluate_registration against the whole memory
 __global__ __launch_bounds__(256) void ibl_evaluate_kernel(ibl_memgrid g, const float4* __restrict__ det, const EvalJob* __restrict__ jobs,
-                                                           float thr, float thr2, double* __restrict__ partial /* [J][BPJ][2] */) {
+                                                           float thr, float thr2, double* __restrict__ partial /* [J][BPJ][2] */,
+                                                           float* __restrict__ d2_out /* per (job, point) or null */) {
     const int j = blockIdx.y;
     const EvalJob job = jobs[j];
     double cnt = 0, err2 = 0;
@@ -1647,6 +1649,7 @@ __global__ __launch_bounds__(256) void ibl_evaluate_kernel(ibl_memgrid g, const 
                     }
                 }
         if (found) { cnt += 1.0; err2 += (double)best; }
+        if (d2_out) d2_out[job.out + (i - job.begin)] = found ? best : INFINITY;
     }
     __shared__ double sh[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1658,9 +1661,24 @@ __global__ __launch_bounds__(256) void ibl_evaluate_kernel(ibl_memgrid g, const 
             ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
 }
 
+static int evaluate_impl(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* det_pts4, const int32_t* job_begin, const int32_t* job_end,
+                         const double* T_global, int n_jobs, double threshold, double* rmse_out, double* fitness_out, float* d2_out, void* stream);
+
 extern "C" int ibl_evaluate_batch(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* det_pts4, const int32_t* job_begin,
                                   const int32_t* job_end, const double* T_global, int n_jobs, double threshold, double* rmse_out,
                                   double* fitness_out, void* stream) {
+    return evaluate_impl(ctx, grid, det_pts4, job_begin, job_end, T_global, n_jobs, threshold, rmse_out, fitness_out, nullptr, stream);
+}
+
+extern "C" int ibl_evaluate_points(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* det_pts4, const int32_t* job_begin,
+                                   const int32_t* job_end, const double* T_global, int n_jobs, double threshold, float* d2_out,
+                                   double* rmse_out, double* fitness_out, void* stream) {
+    if (!d2_out) return ibl_set_error(IBL_ERR_ARG, "ibl_evaluate_points: d2_out is null");
+    return evaluate_impl(ctx, grid, det_pts4, job_begin, job_end, T_global, n_jobs, threshold, rmse_out, fitness_out, d2_out, stream);
+}
+
+static int evaluate_impl(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* det_pts4, const int32_t* job_begin, const int32_t* job_end,
+                         const double* T_global, int n_jobs, double threshold, double* rmse_out, double* fitness_out, float* d2_out, void* stream) {
     if (!ctx || !grid || !det_pts4 || !job_begin || !job_end || !T_global || !rmse_out || !fitness_out || n_jobs <= 0 || threshold <= 0)
         return ibl_set_error(IBL_ERR_ARG, "ibl_evaluate_batch: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -1671,13 +1689,14 @@ extern "C" int ibl_evaluate_batch(ibl_reg_ctx* ctx, const ibl_memgrid* grid, con
         for (int t = 0; t < 12; ++t) jobs[j].T[t] = T_global[16 * j + t];
         jobs[j].begin = job_begin[j]; jobs[j].end = job_end[j];
         if (job_end[j] < job_begin[j]) return ibl_set_error(IBL_ERR_ARG, "ibl_evaluate_batch: bad point range");
+        jobs[j].out = j == 0 ? 0 : jobs[j - 1].out + (jobs[j - 1].end - jobs[j - 1].begin);
     }
     EvalJob* d_jobs; double* partial;
     IBL_ARENA(d_jobs, EvalJob, J);
     IBL_ARENA(partial, double, (int64_t)J * ICP_BPJ * 2);
     IBL_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(EvalJob) * J, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(ibl_evaluate_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, *grid, reinterpret_cast<const float4*>(det_pts4), d_jobs,
-                       (float)threshold, (float)(threshold * threshold), partial);
+                       (float)threshold, (float)(threshold * threshold), partial, d2_out);
     IBL_LAUNCH_CHECK();
     std::vector<double> h((size_t)J * ICP_BPJ * 2);
     IBL_HIP_CHECK(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));

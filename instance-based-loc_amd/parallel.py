@@ -38,3 +38,28 @@ def augment_half(sims: torch.Tensor) -> np.ndarray:
     aug = np.ones((s.shape[0], s.shape[1] + 1), dtype=np.float16)
     aug[:, :-1] = s
     return aug
+
+
+
+def fitness_rmse_from_d2(d2: torch.Tensor, job_sizes):
+    """evaluate_registration's (fitness, inlier rmse) per job from per-point squared distances (+inf = no correspondence)."""
+    fit, rmse = [], []
+    off = 0
+    for n in job_sizes:
+        d = d2[off:off + n]
+        off += n
+        ok = torch.isfinite(d)
+        c = int(ok.sum().item())
+        fit.append(c / n if n else 0.0)
+        rmse.append(float(torch.sqrt(d[ok].double().sum() / c).item()) if c else 0.0)
+    return np.array(fit), np.array(rmse)
+
+
+def evaluate_sharded(local_d2: torch.Tensor, job_sizes, group=None):
+    """Whole-memory evaluation with the memory clouds sharded by instance range: `local_d2` = this rank's
+    `registration.evaluate_points` output against the points it owns; the nearest memory point overall is the minimum over the ranks
+    (all-reduce MIN over RCCL / gloo: 4 bytes per transformed detected point and candidate), then fitness / rmse as on one GPU."""
+    d2 = local_d2.clone()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(d2, op=dist.ReduceOp.MIN, group=group)
+    return fitness_rmse_from_d2(d2, job_sizes)

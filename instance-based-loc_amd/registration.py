@@ -257,3 +257,19 @@ def evaluate_batch(ctx: RegContext, grid: MemGrid, det_pts4: torch.Tensor, job_b
                                      J, float(threshold), rmse.ctypes.data, fit.ctypes.data, _stream())
     _lib.check(st, "ibl_evaluate_batch")
     return rmse, fit
+
+
+def evaluate_points(ctx: RegContext, grid: MemGrid, det_pts4: torch.Tensor, job_begin, job_end, T_global, threshold=0.02):
+    """Per-point form of `evaluate_batch`: squared distance of every transformed detected point to its nearest point of THIS grid within
+    `threshold` (+inf when none) as one float32 device tensor (jobs back to back), plus this grid's own (rmse, fitness)."""
+    jb = np.ascontiguousarray(job_begin, dtype=np.int32)
+    je = np.ascontiguousarray(job_end, dtype=np.int32)
+    T = np.ascontiguousarray(T_global, dtype=np.float64).reshape(-1, 16)
+    J = len(jb)
+    d2 = torch.empty(max(int((je - jb).sum()), 1), dtype=torch.float32, device=det_pts4.device)
+    rmse = np.zeros(J, dtype=np.float64)
+    fit = np.zeros(J, dtype=np.float64)
+    st = _lib.lib.ibl_evaluate_points(ctx.handle, grid.handle, det_pts4.data_ptr(), jb.ctypes.data, je.ctypes.data, T.ctypes.data,
+                                      J, float(threshold), d2.data_ptr(), rmse.ctypes.data, fit.ctypes.data, _stream())
+    _lib.check(st, "ibl_evaluate_points")
+    return d2[:int((je - jb).sum())], rmse, fit

@@ -198,3 +198,37 @@ def test_pipelined_stream_equals_batch_by_batch():
                 assert a.assignments == b.assignments and a.best == b.best
                 assert np.array_equal(a.pose, b.pose) and np.array_equal(a.pose_corrected, b.pose_corrected)
     ctx.close()
+
+
+def test_sharded_evaluate_equals_whole_memory():
+    """ibl_evaluate_points against two instance-range shards of the memory, combined by the element-wise minimum (what the
+    all-reduce(MIN) of parallel.evaluate_sharded does across ranks), gives the whole-memory fitness exactly and its rmse to rounding"""
+    from ibloc_amd.parallel import fitness_rmse_from_d2
+    from ibloc_amd.registration import CloudBatch, MemGrid, RegContext, evaluate_batch, evaluate_points
+    rng = np.random.default_rng(91)
+    ctx = RegContext(2 << 30)
+    mem = [rng.uniform(-1, 1, size=(4000, 3)).astype(np.float32) + rng.uniform(-3, 3, size=3).astype(np.float32) for _ in range(9)]
+    allm = np.concatenate(mem)
+    det = (allm[rng.choice(len(allm), 6000)] + rng.normal(size=(6000, 3)).astype(np.float32) * 0.01).astype(np.float32)
+    det4 = torch.from_numpy(np.concatenate([det, np.zeros((6000, 1), np.float32)], axis=1)).cuda()
+
+    def grid(points):
+        p4 = torch.from_numpy(np.concatenate([points, np.zeros((len(points), 1), np.float32)], axis=1)).cuda().contiguous()
+        return MemGrid(ctx, p4, cell=0.04), p4
+
+    jb, je = [0, 2500, 2500], [2500, 6000, 6000]
+    T = np.stack([np.eye(4), np.eye(4), np.eye(4)])
+    T[2, :3, 3] = [0.004, -0.003, 0.002]
+    g_all, keep_all = grid(allm)
+    g_a, keep_a = grid(np.concatenate(mem[:4]))
+    g_b, keep_b = grid(np.concatenate(mem[4:]))
+    rmse, fit = evaluate_batch(ctx, g_all, det4, jb, je, T, 0.02)
+    d2_all, rmse_p, fit_p = evaluate_points(ctx, g_all, det4, jb, je, T, 0.02)
+    assert np.array_equal(rmse, rmse_p) and np.array_equal(fit, fit_p) and d2_all.numel() == 2500 + 3500 + 3500
+    da, _, _ = evaluate_points(ctx, g_a, det4, jb, je, T, 0.02)
+    db, _, _ = evaluate_points(ctx, g_b, det4, jb, je, T, 0.02)
+    merged = torch.minimum(da, db)
+    assert torch.equal(merged, d2_all)                                   # the nearest point overall is the nearer of the two shards'
+    f2, r2 = fitness_rmse_from_d2(merged, [2500, 3500, 3500])
+    assert np.array_equal(f2, fit) and np.allclose(r2, rmse, rtol=1e-12, atol=0) and 0.3 < fit[0] <= 1.0
+    ctx.close()

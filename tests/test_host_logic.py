@@ -98,3 +98,41 @@ def test_sharded_match_allgather_gloo_world2(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                           "127.0.0.1", "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GLOO_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+EVAL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["IBL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from ibloc_amd.parallel import evaluate_sharded, fitness_rmse_from_d2, shard_range
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(9)                       # same data on every rank
+M, sizes, thr = 11, [400, 250, 0, 333], 0.05
+mem = [rng.uniform(-1, 1, size=(300, 3)) for _ in range(M)]
+det = rng.uniform(-1, 1, size=(sum(sizes), 3))
+def d2_against(points):                              # what ibl_evaluate_points returns for a shard: nearest squared distance within thr
+    d = ((det[:, None, :].astype(np.float32) - points[None, :, :].astype(np.float32)) ** 2).sum(-1).min(axis=1)
+    d[d >= np.float32(thr * thr)] = np.inf
+    return torch.from_numpy(d.astype(np.float32))
+lo, hi = shard_range(M, rank, world)
+local = d2_against(np.concatenate(mem[lo:hi])) if hi > lo else torch.full((len(det),), float("inf"))
+fit, rmse = evaluate_sharded(local, sizes)
+want_fit, want_rmse = fitness_rmse_from_d2(d2_against(np.concatenate(mem)), sizes)
+assert np.array_equal(fit, want_fit) and np.allclose(rmse, want_rmse, rtol=1e-12, atol=0), (fit, want_fit)
+assert fit[2] == 0.0 and rmse[2] == 0.0 and 0 < fit[0] < 1
+dist.barrier()
+if rank == 0:
+    print("EVAL_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_evaluate_allreduce_min_gloo_world2(tmp_path):
+    """SURVEY §8e: memory clouds sharded by instance range, per-point nearest distances combined with all-reduce(MIN)"""
+    script = tmp_path / "eval_worker.py"
+    script.write_text(EVAL_WORKER)
+    env = dict(os.environ, IBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29519", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "EVAL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
