@@ -515,6 +515,7 @@ __device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned 
 // grid (round / (1024 RANSAC_SUBS), active jobs): each block walks 1024 RANSAC_SUBS consecutive hypotheses.  The cheap part (draw + edge-length
 // check, ~99 % rejected) runs on every lane; the survivors of the whole chunk are compacted through LDS so that the
 // expensive part (fp64 Kabsch + distance check) runs once, on densely packed lanes.  `flags` is zeroed by the host before the launch.
+constexpr int RANSAC_LDS_CORR = 1024;    // correspondences staged in LDS (32 KiB)
 template <int RANSAC_SUBS>               // 1024-hypothesis passes per block (one Kabsch pass over all their survivors)
 __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
@@ -532,9 +533,16 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
     const float4* c = cp + 2 * (int64_t)job_off[j];
     const int nc = n_corr[j];
     const unsigned job_id = job_id_base + (unsigned)j;
-    __shared__ int surv[RANSAC_CHUNK];
+    __shared__ unsigned short surv[RANSAC_CHUNK];     // slot within the chunk
     __shared__ int nsurv;
     __shared__ int cnt16[4 * RANSAC_SUBS];
+    // The packed correspondences of the job (32 B each) are drawn 3 at a time by every hypothesis: random 16-byte gathers that sat on
+    // L2 latency with two waves per SIMD to hide it.  Up to RANSAC_LDS_CORR of them are staged in LDS once per block (a block draws
+    // from them 6 x 4096 ... 16384 times); larger jobs keep reading global memory.  Same values either way.
+    __shared__ float4 sc[2 * RANSAC_LDS_CORR];
+    const bool in_lds = nc <= RANSAC_LDS_CORR;
+    if (in_lds && job_on)
+        for (int t = threadIdx.x; t < 2 * nc; t += 256) sc[t] = c[t];
     if (threadIdx.x < 4 * RANSAC_SUBS) cnt16[threadIdx.x] = 0;
     if (threadIdx.x == 0) nsurv = 0;
     __syncthreads();
@@ -544,20 +552,23 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
         const int slot = blockIdx.x * RANSAC_CHUNK + r * 256 + threadIdx.x;
         const long long i = next_i + slot;
         bool ok = false;
-        if (job_on && i < est_k && i < max_iter) ok = ransac_edge_ok_draw(i, job_id, seed_lo, seed_hi, c, nc, edge_sim, e2_lo, e2_hi);
+        if (job_on && i < est_k && i < max_iter)
+            ok = in_lds ? ransac_edge_ok_draw(i, job_id, seed_lo, seed_hi, sc, nc, edge_sim, e2_lo, e2_hi)
+                        : ransac_edge_ok_draw(i, job_id, seed_lo, seed_hi, c, nc, edge_sim, e2_lo, e2_hi);
         const unsigned long long m = __ballot(ok);
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(&nsurv, __popcll(m));
         base = __shfl(base, 0, 64);
-        if (ok) surv[base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+        if (ok) surv[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(r * 256 + threadIdx.x);
     }
     __syncthreads();
     // the survivors of the whole chunk (~1 %) go through the fp64 Kabsch together: a single, densely packed pass
     const int ns = nsurv;
     for (int t = threadIdx.x; t < ns; t += 256) {
-        const int slot = surv[t];
+        const int slot = blockIdx.x * RANSAC_CHUNK + (int)surv[t];
         double sp[9], dp[9], T[16];
-        ransac_draw(next_i + slot, job_id, seed_lo, seed_hi, c, nc, sp, dp);
+        if (in_lds) ransac_draw(next_i + slot, job_id, seed_lo, seed_hi, sc, nc, sp, dp);
+        else ransac_draw(next_i + slot, job_id, seed_lo, seed_hi, c, nc, sp, dp);
         if (ransac_fit_ok(sp, dp, max_dist, T)) {
             flags[(int64_t)a * round_size + slot] = 1;
             atomicAdd(&cnt16[(slot - blockIdx.x * RANSAC_CHUNK) >> 8], 1);
