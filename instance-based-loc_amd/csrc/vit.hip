@@ -505,7 +505,9 @@ __global__ void ibl_set_cls_kernel(float* __restrict__ x, const float* __restric
 // Attention: one workgroup (4 waves) per (crop, head); head_dim = 64; T <= 16 * NT.
 // qkv bf16 [B*T][3*D] = [q | k | v], each [heads][64].   out bf16 [B*T][D].
 // ------------------------------------------------------------------------------------------------
+#ifndef ATT_THREADS
 #define ATT_THREADS 512
+#endif
 template <int NT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
                                                             int D, int heads, float scale, int cls_only) {
