@@ -37,7 +37,7 @@ const char* ibl_last_error(void);
 /* In-process kernel timer for the roofline line of bench.py: when enabled, selected kernel families are
  * bracketed by HIP events ON THEIR LAUNCH STREAM.  ibl_prof_read synchronises those events and returns the
  * accumulated device time, the accumulated algorithmic units (FLOPs or bytes, see csrc/ibl_common.h) and the
- * number of launches of family `id` (1 = bf16 GEMM, 3 = SPFH k-NN, ...). */
+ * number of launches of family `id` (1 = fp16 GEMM, 3 = SPFH k-NN, ...). */
 int ibl_prof_enable(int on);
 int ibl_prof_read(int id, double* ms, double* units, int64_t* launches);
 
@@ -64,7 +64,7 @@ typedef struct {
     float ln_eps;
 } ibl_vit_desc;
 
-typedef struct {                   /* all [dev]; weights bf16 [N][K] row-major (nn.Linear layout)   */
+typedef struct {                   /* all [dev]; weights fp16 [N][K] row-major (nn.Linear layout)   */
     const float* ln1_g; const float* ln1_b;
     const void* w_qkv;  const float* b_qkv;     /* [3*dim][dim] = [Wq; Wk; Wv], [3*dim]              */
     const void* w_o;    const float* b_o;       /* [dim][dim]                                         */
@@ -76,14 +76,14 @@ typedef struct {                   /* all [dev]; weights bf16 [N][K] row-major (
 } ibl_vit_layer;
 
 typedef struct {
-    const void* w_patch;           /* bf16 [dim][patch_k_pad]: conv weight flattened (c, kh, kw)     */
+    const void* w_patch;           /* fp16 [dim][patch_k_pad]: conv weight flattened (c, kh, kw)     */
     const float* b_patch;          /* [dim] or NULL                                                  */
     const float* cls_pos;          /* [dim]: cls_token + position_embedding[0]                       */
     const float* pos_patch;        /* [n_tokens-1][dim]: position embeddings of the patch tokens,
                                       already interpolated to the (img_h/patch, img_w/patch) grid    */
     const float* ln_pre_g; const float* ln_pre_b;
     const float* ln_f_g;   const float* ln_f_b;
-    const void* w_proj;            /* bf16 [out_dim][dim] or NULL                                    */
+    const void* w_proj;            /* fp16 [out_dim][dim] or NULL                                    */
     ibl_vit_layer layers[IBL_VIT_MAX_LAYERS];
 } ibl_vit_weights;
 
@@ -102,7 +102,7 @@ typedef struct {
 } ibl_crop_desc;
 
 /* u8 crops -> (optional R<->B swap, utils/embeddings.py:41,64,86) -> PIL-exact resize ->
- * window (centre crop) -> ((u8/255) - mean) / std -> bf16 im2col patch matrix
+ * window (centre crop) -> ((u8/255) - mean) / std -> fp16 im2col patch matrix
  * [n_crops * (out_h/patch)*(out_w/patch)][patch_k_pad], k = c*patch*patch + kh*patch + kw.
  *   max_in_h: tallest crop of the batch (sizes the launch);
  *   src, tables, descs, tmp: [dev];  mean/stdv: 3 floats each (host), indexed by MODEL channel
@@ -114,7 +114,7 @@ int ibl_preprocess_crops(const uint8_t* src, const ibl_crop_desc* descs, int n_c
 
 /* ViT forward over a batch of crops.  Replaces the batch-1 torch forward of
  * utils/embeddings.py:46,69,93 and dator/model/backbones/vit_pytorch.py:422-443.
- *   patches [dev] bf16 [batch*(n_tokens-1)][patch_k_pad] (from ibl_preprocess_crops)
+ *   patches [dev] fp16 [batch*(n_tokens-1)][patch_k_pad] (from ibl_preprocess_crops)
  *   out     [dev] fp32 [batch][out_dim]  (CLS embedding; un-normalised, like the reference), or
  *           fp32 [batch][n_tokens][dim] with IBL_VIT_OUT_ALL_TOKENS */
 int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* desc, int batch);
@@ -123,12 +123,12 @@ int ibl_vit_forward(const ibl_vit_desc* desc, const ibl_vit_weights* weights, co
 
 /* One linear layer of the encoder on its own: out = epilogue(x W^T + bias).  The nn.Linear of the reference's
  * encoders (transformers' ViTSelfAttention / ViTIntermediate / ViTOutput called from utils/embeddings.py:46,69,93).
- *   x [dev] bf16 [rows][ldx], W [dev] bf16 [n_out][ldw] (nn.Linear layout), bias [dev] fp32 [n_out] or NULL
- *   epilogue: IBL_LINEAR_BF16 -> out bf16; IBL_LINEAR_GELU_BF16 -> out = gelu(.) bf16 (erf form);
+ *   x [dev] fp16 [rows][ldx], W [dev] fp16 [n_out][ldw] (nn.Linear layout), bias [dev] fp32 [n_out] or NULL
+ *   epilogue: IBL_LINEAR_F16 -> out fp16; IBL_LINEAR_GELU_F16 -> out = gelu(.) fp16 (erf form);
  *             IBL_LINEAR_RESID_F32 -> out fp32 += scale[n] * (.) (scale NULL = 1); IBL_LINEAR_F32 -> out fp32
  *   n_out % 128 == 0, n_in % 64 == 0, ldx / ldw / ldo in elements with 16-byte aligned rows */
-enum { IBL_LINEAR_BF16 = 0, IBL_LINEAR_GELU_BF16 = 1, IBL_LINEAR_RESID_F32 = 2, IBL_LINEAR_F32 = 4 };
-int ibl_linear_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, const float* scale,
+enum { IBL_LINEAR_F16 = 0, IBL_LINEAR_GELU_F16 = 1, IBL_LINEAR_RESID_F32 = 2, IBL_LINEAR_F32 = 4 };
+int ibl_linear_f16(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, const float* scale,
                     int64_t rows, int n_out, int n_in, int epilogue, void* out, int64_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -156,7 +156,7 @@ int64_t ibl_dator_head_workspace_bytes(int batch);
 int ibl_dator_head_forward(const ibl_dator_head_weights* w, const float* rgb_tokens, const float* depth_tokens, int batch,
                            float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Depth crops (float, [dev], crop i = sizes[2i] x sizes[2i+1] floats at src + offsets[i]) -> bf16 patch matrix of the
+/* Depth crops (float, [dev], crop i = sizes[2i] x sizes[2i+1] floats at src + offsets[i]) -> fp16 patch matrix of the
  * depth stream: bilinear resize to out_h x out_w (cv2.INTER_LINEAR convention), clip [dmin, dmax], (d - dmin)/(dmax - dmin),
  * (x - 0.5)/0.5, three identical channels (dator/get_embeds.py:129-136; the reference's dator_wrapper is missing). */
 int ibl_preprocess_depth(const float* src, const int64_t* offsets, const int32_t* sizes, int n_crops, int out_h, int out_w,

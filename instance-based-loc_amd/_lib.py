@@ -45,7 +45,7 @@ _SIGS = {
     "ibl_preprocess_crops": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        vp, vp, vp, vp, vp]),
     "ibl_vit_workspace_bytes": (C.c_int64, [vp, C.c_int]),
-    "ibl_linear_bf16": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),
+    "ibl_linear_f16": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp]),
     "ibl_vit_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),
     "ibl_reg_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int64]),
     "ibl_reg_ctx_destroy": (C.c_int, [vp]),

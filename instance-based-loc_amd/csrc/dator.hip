@@ -7,7 +7,7 @@
 // a generic LDS-tiled fp32 linear, a token-major 3x3 convolution for the hyper-network, the deformable bilinear
 // sampler (F.grid_sample semantics: align_corners=True, zero padding), residual + gate + LayerNorm, gated mean.
 #include <hip/hip_runtime.h>
-#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include "ibl_common.h"
 #include "ibloc.h"
@@ -284,7 +284,7 @@ extern "C" int ibl_dator_head_forward(const ibl_dator_head_weights* w, const flo
 
 // ------------------------------------------------------------------------------------------------
 // depth preprocessing: bilinear resize (cv2.INTER_LINEAR convention) -> clip -> scale -> normalise -> 3 identical
-// channels -> bf16 im2col patch matrix of the depth stream
+// channels -> fp16 im2col patch matrix of the depth stream
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ibl_depth_prep_kernel(const float* __restrict__ src, const int64_t* __restrict__ offs,
                                                              const int* __restrict__ sizes, int out_h, int out_w, int patch, int kpad,
@@ -315,8 +315,7 @@ __global__ __launch_bounds__(256) void ibl_depth_prep_kernel(const float* __rest
     r = fminf(fmaxf(r, dmin), dmax);
     r = (r - dmin) / (dmax - dmin);
     r = (r - 0.5f) / 0.5f;
-    __hip_bfloat16 hb = __float2bfloat16(r);
-    const unsigned short v = *reinterpret_cast<unsigned short*>(&hb);
+    const unsigned short v = __builtin_bit_cast(unsigned short, (_Float16)r);
     const int gw = out_w / patch;
     const int py = oy / patch, ky = oy - py * patch, px = ox / patch, kx = ox - px * patch;
     const int64_t prow = (int64_t)b * (out_h / patch) * gw + py * gw + px;

@@ -1,5 +1,5 @@
 // preprocess.hip -- object-crop preprocessing on gfx950: PIL-exact separable u8 resample (bicubic /
-// bilinear with antialiasing), centre-crop window, channel swap, normalisation, im2col to the bf16
+// bilinear with antialiasing), centre-crop window, channel swap, normalisation, im2col to the fp16
 // patch matrix the patch-embedding GEMM consumes.
 //
 // Replaces the CPU PIL / HF-processor step of every reference embedding function
@@ -8,7 +8,7 @@
 // a u8 intermediate), so the u8 result is bit-identical to PIL.Image.resize; the coefficient tables
 // are computed on the host in float64 exactly as Pillow's precompute_coeffs does.
 #include <hip/hip_runtime.h>
-#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include "ibl_common.h"
 #include "ibloc.h"
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void ibl_resample_v_kernel(const unsigned char
         const unsigned char u = px[swap_rb ? 2 - c : c];
         const float r = (float)((double)u * (1.0 / 255.0));
         const float v = (r - mm[c]) / ss[c];
-        __hip_bfloat16 h = __float2bfloat16(v);
-        patches[prow * patch_k_pad + c * patch * patch + ky * patch + kx] = *reinterpret_cast<unsigned short*>(&h);
+        const _Float16 h = (_Float16)v;        // fp16 operand of the patch-embedding GEMM (round to nearest even)
+        patches[prow * patch_k_pad + c * patch * patch + ky * patch + kx] = __builtin_bit_cast(unsigned short, h);
     }
 }
 

@@ -1,4 +1,4 @@
-// vit.hip -- ViT encoder forward on gfx950 (bf16 MFMA 16x16x32, fp32 accumulate, fp32 residual).
+// vit.hip -- ViT encoder forward on gfx950 (fp16 MFMA 16x16x32, fp32 accumulate, fp32 residual).
 //
 // Replaces the torch/cuDNN forward the reference reaches through
 //   utils/embeddings.py:46 (CLIP ViT-B/32), :69 (DINOv2), :93 (ViT-B/16), :119 (DATOR streams,
@@ -6,43 +6,41 @@
 // one crop at a time; here a whole batch of crops runs per call.
 //
 // HBM layout (all row-major, token-major): residual stream x fp32 [B*T][D]; LayerNorm output,
-// QKV, attention output and MLP hidden as bf16; weights bf16 [N][K] (K contiguous, i.e. the
+// QKV, attention output and MLP hidden as fp16 (11-bit significand: rel-L2 1.2e-3 on the 12-layer ViT-B/14 where bf16 operands gave 1.1e-2, same MFMA rate); weights fp16 [N][K] (K contiguous, i.e. the
 // nn.Linear layout) so that both MFMA operands are 16-byte K-contiguous fragments.
 //
-// Kernels: gemm_bf16_tn (128x128x64 LDS-tiled, register-staged double buffer, fused epilogues:
+// Kernels: gemm_f16_tn (128x128x64 LDS-tiled, register-staged double buffer, fused epilogues:
 // bias / bias+GELU / bias*layerscale+residual / patch-embed scatter+pos-embed), layernorm (one
 // wave per row), attention (one workgroup per (crop, head), K and V^T of the head staged in LDS,
 // S^T = K Q^T so that the softmaxed probabilities are already the A operand of P V), CLS/final
 // LayerNorm.
 #include <hip/hip_runtime.h>
-#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include "ibl_common.h"
 #include "ibloc.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short u16;
 
-__device__ __forceinline__ u16 f2bf(float f) {   // round-to-nearest-even, NaN preserved by the hw cvt
-    __hip_bfloat16 b = __float2bfloat16(f);
-    return *reinterpret_cast<u16*>(&b);
-}
-__device__ __forceinline__ float bf2f(u16 h) {
-    unsigned int u = (unsigned int)h << 16;
-    return __uint_as_float(u);
+// fp32 -> fp16 operand, round-to-nearest-even (v_cvt_f16_f32), clamped to the finite range: an activation beyond 65504 would
+// otherwise become an infinity and poison the row (not reached by ViT-B activations; the residual stream itself stays fp32)
+__device__ __forceinline__ u16 f2h(float f) {
+    const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+    return __builtin_bit_cast(u16, h);
 }
 
 // ------------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] * W[N][K]^T  (+ epilogue)
 // ------------------------------------------------------------------------------------------------
-enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_PATCH_F32 = 3, EPI_BIAS_F32 = 4 };
+enum { EPI_BIAS_H16 = 0, EPI_BIAS_GELU_H16 = 1, EPI_RESID_F32 = 2, EPI_PATCH_F32 = 3, EPI_BIAS_F32 = 4 };
 
 struct GemmEpi {
     const float* bias;      // [N] or null
     const float* scale;     // [N] LayerScale or null (EPI_RESID)
     const float* pos;       // [P][N] position embedding rows for patches (EPI_PATCH)
-    void* out;              // bf16 or fp32
+    void* out;              // fp16 or fp32
     int64_t ldo;            // output row stride (elements)
     int tokens_per_crop;    // T (EPI_PATCH)
     int patches_per_crop;   // P (EPI_PATCH)
@@ -74,7 +72,7 @@ template <int BK> __device__ __forceinline__ int keyx_pair(int r) { return BK ==
 // (global_load_lds_dwordx4): one wave instruction writes 1 KiB = 8 tile rows linearly, so the XOR swizzle is applied
 // to the per-lane SOURCE address.
 // Exact-form GELU, 0.5 v (1 + erf(v / sqrt 2)), with erfc from Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7 in erf, two orders
-// below the bf16 rounding of the stored activation).  libm's erff costs ~35 VALU instructions per element, which made the
+// below the fp16 rounding of the stored activation).  libm's erff costs ~35 VALU instructions per element, which made the
 // fc1 epilogue as long as its K loop; this form is 14.
 __device__ __forceinline__ float gelu_erf(float v) {
     const float z = fabsf(v) * 0.70710678118654752f;
@@ -104,7 +102,7 @@ extern "C" int ibl_gemm_stamps_read(long long* dst, int n) {
 #endif
 
 template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS>
-__global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
+__global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
                                                                   int64_t ldw, int M, int N, int K, GemmEpi epi) {
     constexpr int BM = WM * MI * 16, BN = WN * 64, NW = WM * WN;
     constexpr int LDS_ROW = BK * 2;          // bytes per tile row, XOR-swizzled 16-byte chunks (no padding)
@@ -118,12 +116,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
     const int wm = wave / WN, wn = wave % WN;
     // fp32 read-modify-write epilogue: MFMA row 4 fg + r of n-tile j is weight row 16 j + 4 fg + r (natural order), so that one
     // wave instruction covers 64 contiguous bytes of each of its 16 output rows; with the 16-consecutive-columns-per-lane map
-    // of the bf16 epilogues every float4 instruction touched 64 separate cache lines and the address coalescer (not HBM) bound
+    // of the fp16 epilogues every float4 instruction touched 64 separate cache lines and the address coalescer (not HBM) bound
     // the epilogue: 52 k clocks per tile, more than the projection's K loop.
     constexpr bool NAT = EPI == EPI_RESID_F32;
-    // bf16 epilogues: MFMA row 4 fg + r of n-tile j is weight row 32 (j / 2) + 8 fg + 4 (j % 2) + r: a lane owns 8 consecutive
+    // fp16 epilogues: MFMA row 4 fg + r of n-tile j is weight row 32 (j / 2) + 8 fg + 4 (j % 2) + r: a lane owns 8 consecutive
     // columns (one 16-byte store) of n-tile pair j / 2 and the four lane groups cover 64 contiguous bytes of the row
-    constexpr bool PAIR = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16;
+    constexpr bool PAIR = EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16;
 #define KEYW(r) (NAT ? keyx_act<BK>(r) : (PAIR ? keyx_pair<BK>(r) : keyx_w<BK>(r)))
     // XCD-aware remap: consecutive tiles along N (sharing the A panel) stay on one XCD's L2
     const int nbn = N / BN;
@@ -206,16 +204,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int ch = 4 * ks + fg;
-            bf16x8 af[MI], wf[4];
+            h16x8 af[MI], wf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + wrow[j] * LDS_ROW + ((ch ^ KEYW(wrow[j])) << 4));
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const h16x8*>(pw + wrow[j] * LDS_ROW + ((ch ^ KEYW(wrow[j])) << 4));
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ keyx_act<BK>(arow[i])) << 4));
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const h16x8*>(pa + arow[i] * LDS_ROW + ((ch ^ keyx_act<BK>(arow[i])) << 4));
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
                 const int g = ks * MI + i;
 #pragma unroll
                 // pieces are issued over the first half of the step's groups: one issued in the last groups has not landed at the
@@ -299,11 +297,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     v[t] = acc[i][2 * j2 + (t >> 2)][t & 3] + bb[j2][t];
-                    if (EPI == EPI_BIAS_GELU_BF16) v[t] = gelu_erf(v[t]);
+                    if (EPI == EPI_BIAS_GELU_H16) v[t] = gelu_erf(v[t]);
                 }
                 *reinterpret_cast<uint4*>(orow + 32 * j2) =
-                    make_uint4((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16),
-                               (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16), (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16));
+                    make_uint4((unsigned)f2h(v[0]) | ((unsigned)f2h(v[1]) << 16), (unsigned)f2h(v[2]) | ((unsigned)f2h(v[3]) << 16),
+                               (unsigned)f2h(v[4]) | ((unsigned)f2h(v[5]) << 16), (unsigned)f2h(v[6]) | ((unsigned)f2h(v[7]) << 16));
             }
         }
 #ifdef IBL_GEMM_STAMPS
@@ -332,14 +330,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_bf16_tn(const u16*
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
-        if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
-            if (EPI == EPI_BIAS_GELU_BF16) {
+        if (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
+            if (EPI == EPI_BIAS_GELU_H16) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) v[t] = gelu_erf(v[t]);
             }
             unsigned int pk[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) pk[t] = (unsigned int)f2bf(v[2 * t]) | ((unsigned int)f2bf(v[2 * t + 1]) << 16);
+            for (int t = 0; t < 8; ++t) pk[t] = (unsigned int)f2h(v[2 * t]) | ((unsigned int)f2h(v[2 * t + 1]) << 16);
             uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<u16*>(epi.out) + (int64_t)row * epi.ldo + n0);
             o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -382,13 +380,13 @@ static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw,
     const size_t lds = NS * (size_t)(BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC, NS>),
+        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     void* tok;
     ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);
-    hipLaunchKernelGGL((ibl_gemm_bf16_tn<EPI, MI, WM, WN, BK, OCC, NS>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
@@ -427,7 +425,7 @@ static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, fp32 in -> bf16 out (or fp32 out for the final CLS rows)
+// LayerNorm: one wave per row, fp32 in -> fp16 out (or fp32 out for the final CLS rows)
 // ------------------------------------------------------------------------------------------------
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void ibl_layernorm_kernel(const float* x, int64_t in_row_stride,
@@ -481,7 +479,7 @@ __global__ __launch_bounds__(256) void ibl_layernorm_kernel(const float* x, int6
                     make_float4(y0, y1, y2, y3);
             } else {
                 ushort4 o;
-                o.x = f2bf(y0); o.y = f2bf(y1); o.z = f2bf(y2); o.w = f2bf(y3);
+                o.x = f2h(y0); o.y = f2h(y1); o.z = f2h(y2); o.w = f2h(y3);
                 *reinterpret_cast<ushort4*>(reinterpret_cast<u16*>(out) + row * out_row_stride + c0) = o;
             }
         }
@@ -489,7 +487,7 @@ __global__ __launch_bounds__(256) void ibl_layernorm_kernel(const float* x, int6
     for (int i = rem0 + lane; i < dim; i += 64, ++t) {
         const float y = (tail[t] - mean) * rstd * g[i] + b[i];
         if (OUT_F32) reinterpret_cast<float*>(out)[row * out_row_stride + i] = y;
-        else reinterpret_cast<u16*>(out)[row * out_row_stride + i] = f2bf(y);
+        else reinterpret_cast<u16*>(out)[row * out_row_stride + i] = f2h(y);
     }
 }
 
@@ -503,7 +501,7 @@ __global__ void ibl_set_cls_kernel(float* __restrict__ x, const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 // Attention: one workgroup (4 waves) per (crop, head); head_dim = 64; T <= 16 * NT.
-// qkv bf16 [B*T][3*D] = [q | k | v], each [heads][64].   out bf16 [B*T][D].
+// qkv fp16 [B*T][3*D] = [q | k | v], each [heads][64].   out fp16 [B*T][D].
 // ------------------------------------------------------------------------------------------------
 #ifndef ATT_THREADS
 #define ATT_THREADS 512
@@ -512,7 +510,7 @@ template <int NT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
                                                             int D, int heads, float scale, int cls_only) {
     constexpr int KEYS = NT * 16;
-    constexpr int KROW = 144;               // bytes per K row (64 bf16 + 16 B pad)
+    constexpr int KROW = 144;               // bytes per K row (64 fp16 + 16 B pad)
     constexpr int VROW = KEYS * 2 + 16;     // bytes per V^T row
     __shared__ __attribute__((aligned(16))) unsigned char sK[KEYS * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char sV[64 * VROW];
@@ -557,8 +555,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
         int qrow = qt * 16 + fr;
         if (qrow >= T) qrow = T - 1;
         const u16* qp = qbase + (int64_t)qrow * ld + fg * 8;
-        const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
-        const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+        const h16x8 qf0 = *reinterpret_cast<const h16x8*>(qp);
+        const h16x8 qf1 = *reinterpret_cast<const h16x8*>(qp + 32);
 
         // S^T tiles: acc[t][r] = S[q = fr][key = 16 t + 4 g + r]
         f32x4 sc[NT];
@@ -566,11 +564,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const unsigned char* kp = sK + (t * 16 + fr) * KROW + fg * 16;
-            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp);
-            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp + 64);
+            const h16x8 k0 = *reinterpret_cast<const h16x8*>(kp);
+            const h16x8 k1 = *reinterpret_cast<const h16x8*>(kp + 64);
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf1, a, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = t * 16 + fg * 4 + r;
@@ -605,11 +603,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
         constexpr int NS = (NT + 1) / 2;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            bf16x8 pf;
+            h16x8 pf;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                pf[j] = (__bf16)sc[2 * s][j];
-                pf[4 + j] = (2 * s + 1 < NT) ? (__bf16)sc[(2 * s + 1 < NT) ? 2 * s + 1 : 0][j] : (__bf16)0.0f;
+                pf[j] = (_Float16)sc[2 * s][j];
+                pf[4 + j] = (2 * s + 1 < NT) ? (_Float16)sc[(2 * s + 1 < NT) ? 2 * s + 1 : 0][j] : (_Float16)0.0f;
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -618,13 +616,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
                 uint2 hi = make_uint2(0, 0);
                 if (2 * s + 1 < NT) hi = *reinterpret_cast<const uint2*>(vp + 32);
                 uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&packed);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);     // O^T tile: rows = d, columns = q
+                const h16x8 vf = *reinterpret_cast<const h16x8*>(&packed);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);     // O^T tile: rows = d, columns = q
             }
             asm volatile("" ::: "memory");
         }
         // O^T layout: row = d = 16 dt + 4 g + r, col = q = fr -> a lane owns four consecutive head dimensions of ONE query row
-        // (8-byte stores; the untransposed product left it with single bf16 elements of four rows) and that row's softmax
+        // (8-byte stores; the untransposed product left it with single fp16 elements of four rows) and that row's softmax
         // sum is already on this lane (it was reduced over the lane groups above).
         const int qg = qt * 16 + fr;
         if (qg < (cls_only ? 1 : T)) {
@@ -633,8 +631,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 pk;
-                pk.x = (unsigned)f2bf(o[dt][0] * inv) | ((unsigned)f2bf(o[dt][1] * inv) << 16);
-                pk.y = (unsigned)f2bf(o[dt][2] * inv) | ((unsigned)f2bf(o[dt][3] * inv) << 16);
+                pk.x = (unsigned)f2h(o[dt][0] * inv) | ((unsigned)f2h(o[dt][1] * inv) << 16);
+                pk.y = (unsigned)f2h(o[dt][2] * inv) | ((unsigned)f2h(o[dt][3] * inv) << 16);
                 *reinterpret_cast<uint2*>(orow + dt * 16) = pk;
             }
         }
@@ -646,13 +644,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
 // ------------------------------------------------------------------------------------------------
 static inline int64_t rows_pad(int64_t r) { return ibl_align_up(r, 128); }
 
-extern "C" int ibl_linear_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, const float* scale,
+extern "C" int ibl_linear_f16(const void* x, int64_t ldx, const void* W, int64_t ldw, const float* bias, const float* scale,
                                int64_t rows, int n_out, int n_in, int epilogue, void* out, int64_t ldo, void* stream) {
     if (rows == 0) return IBL_OK;
-    if (!x || !W || !out) return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: null operand");
-    if (rows < 0 || rows > 0x7fffffff) return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: rows out of range");
+    if (!x || !W || !out) return ibl_set_error(IBL_ERR_ARG, "ibl_linear_f16: null operand");
+    if (rows < 0 || rows > 0x7fffffff) return ibl_set_error(IBL_ERR_ARG, "ibl_linear_f16: rows out of range");
     if ((ldx & 7) || (ldw & 7) || ldx < n_in || ldw < n_in || ldo < n_out || (ldo & 7))
-        return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: row strides must be >= the row length and multiples of 8 elements");
+        return ibl_set_error(IBL_ERR_ARG, "ibl_linear_f16: row strides must be >= the row length and multiples of 8 elements");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     GemmEpi e{};
     e.bias = bias;
@@ -662,11 +660,11 @@ extern "C" int ibl_linear_bf16(const void* x, int64_t ldx, const void* W, int64_
     const u16* a = reinterpret_cast<const u16*>(x);
     const u16* w = reinterpret_cast<const u16*>(W);
     switch (epilogue) {
-        case EPI_BIAS_BF16: return launch_gemm<EPI_BIAS_BF16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
-        case EPI_BIAS_GELU_BF16: return launch_gemm<EPI_BIAS_GELU_BF16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
+        case EPI_BIAS_H16: return launch_gemm<EPI_BIAS_H16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
+        case EPI_BIAS_GELU_H16: return launch_gemm<EPI_BIAS_GELU_H16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
         case EPI_RESID_F32: return launch_gemm<EPI_RESID_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
         case EPI_BIAS_F32: return launch_gemm<EPI_BIAS_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
-        default: return ibl_set_error(IBL_ERR_ARG, "ibl_linear_bf16: unknown epilogue %d", epilogue);
+        default: return ibl_set_error(IBL_ERR_ARG, "ibl_linear_f16: unknown epilogue %d", epilogue);
     }
 }
 
@@ -679,7 +677,7 @@ extern "C" int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* d, int batch) {
     bytes += R * 3 * d->dim * 2;      // qkv
     bytes += R * d->dim * 2;          // attn out
     bytes += R * d->mlp_dim * 2;      // mlp hidden
-    bytes += rows_pad(batch) * d->dim * 2 + rows_pad(batch) * d->dim * 4;  // final rows (bf16 + f32)
+    bytes += rows_pad(batch) * d->dim * 2 + rows_pad(batch) * d->dim * 4;  // final rows (fp16 + f32)
     return bytes + 6 * 256;
 }
 
@@ -751,7 +749,7 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
     }
     const dim3 ln_grid((unsigned)((Rn + 3) / 4));
     if (d->flags & IBL_VIT_PRE_LN) {
-        // CLIP ln_pre: normalise the residual stream in place (through the bf16-free f32 path)
+        // CLIP ln_pre: normalise the residual stream in place (through the fp16-free f32 path)
         hipLaunchKernelGGL(ibl_layernorm_kernel<true>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, w->ln_pre_g,
                            w->ln_pre_b, d->ln_eps, (void*)x, (int64_t)D);
         IBL_LAUNCH_CHECK();
@@ -770,16 +768,16 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
         if (!cls_only) {
             GemmEpi e{};
             e.bias = L->b_qkv; e.out = qkv; e.ldo = 3 * D;
-            st = launch_gemm<EPI_BIAS_BF16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv), D, (int)Rn, 3 * D, D, e, s);
+            st = launch_gemm<EPI_BIAS_H16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv), D, (int)Rn, 3 * D, D, e, s);
             if (st) return st;
         } else {
             GemmEpi e{};                                  // keys and values of every token: weight rows D .. 3D
             e.bias = L->b_qkv + D; e.out = qkv + D; e.ldo = 3 * D;
-            st = launch_gemm<EPI_BIAS_BF16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv) + (int64_t)D * D, D, (int)Rn, 2 * D, D, e, s);
+            st = launch_gemm<EPI_BIAS_H16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv) + (int64_t)D * D, D, (int)Rn, 2 * D, D, e, s);
             if (st) return st;
             GemmEpi q{};                                  // queries of the CLS rows only
             q.bias = L->b_qkv; q.out = qkv; q.ldo = 3 * TD;
-            st = launch_gemm<EPI_BIAS_BF16>(xn, TD, reinterpret_cast<const u16*>(L->w_qkv), D, batch, D, D, q, s);
+            st = launch_gemm<EPI_BIAS_H16>(xn, TD, reinterpret_cast<const u16*>(L->w_qkv), D, batch, D, D, q, s);
             if (st) return st;
         }
         st = run_attention(qkv, att, batch, T, D, H, cls_only ? 1 : 0, s);
@@ -806,7 +804,7 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
             e.bias = L->b_fc1; e.out = hid; e.ldo = d->mlp_dim;
             if (d->flags & IBL_VIT_QUICK_GELU)
                 return ibl_set_error(IBL_ERR_UNSUPPORTED, "ibl_vit_forward: QuickGELU not built");
-            st = launch_gemm<EPI_BIAS_GELU_BF16>(mlp_in, D, reinterpret_cast<const u16*>(L->w_fc1), D, mlp_rows, d->mlp_dim, D, e, s);
+            st = launch_gemm<EPI_BIAS_GELU_H16>(mlp_in, D, reinterpret_cast<const u16*>(L->w_fc1), D, mlp_rows, d->mlp_dim, D, e, s);
             if (st) return st;
         }
         {

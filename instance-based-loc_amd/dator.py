@@ -102,30 +102,38 @@ class DatorEncoder:
         self._ws = None
 
     def preprocess_depth(self, depth_crops) -> torch.Tensor:
-        """list of (h, w) float depth crops -> bf16 patch matrix of the depth stream (bilinear resize to 256x128, 3 identical
-        channels, clip, scale, normalise)."""
-        n = len(depth_crops)
-        sizes = np.array([[c.shape[0], c.shape[1]] for c in depth_crops], dtype=np.int32)
+        """list of (h, w) float depth crops, or one float32 tensor (N, h, w) of equally sized crops (host or device) -> fp16 patch
+        matrix of the depth stream (bilinear resize to 256x128, 3 identical channels, clip, scale, normalise)."""
+        if isinstance(depth_crops, torch.Tensor):
+            n, h, w = depth_crops.shape
+            sizes = np.tile(np.array([[h, w]], dtype=np.int32), (n, 1))
+            flat = depth_crops.to(self.device, torch.float32).contiguous().view(-1)
+        else:
+            n = len(depth_crops)
+            sizes = np.array([[c.shape[0], c.shape[1]] for c in depth_crops], dtype=np.int32)
+            flat = torch.from_numpy(np.concatenate([np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in depth_crops])).to(self.device)
         offs = np.concatenate([[0], np.cumsum(sizes[:, 0].astype(np.int64) * sizes[:, 1])]).astype(np.int64)
-        flat = torch.from_numpy(np.concatenate([np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in depth_crops])).to(self.device)
         d_sizes = torch.from_numpy(sizes).to(self.device)
         d_offs = torch.from_numpy(offs).to(self.device)
         cfg = STREAM_CFG
-        patches = torch.empty((n * (cfg.n_tokens - 1), cfg.patch_k_pad), dtype=torch.bfloat16, device=self.device)
+        patches = torch.empty((n * (cfg.n_tokens - 1), cfg.patch_k_pad), dtype=torch.float16, device=self.device)
         st = _lib.lib.ibl_preprocess_depth(flat.data_ptr(), d_offs.data_ptr(), d_sizes.data_ptr(), n, cfg.img_h, cfg.img_w, cfg.patch,
                                            cfg.patch_k_pad, float(MIN_DEPTH), float(MAX_DEPTH), patches.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "ibl_preprocess_depth")
         return patches
 
-    def head(self, rgb_tokens: torch.Tensor, depth_tokens: torch.Tensor) -> torch.Tensor:
+    def head(self, rgb_tokens: torch.Tensor, depth_tokens: torch.Tensor, lane: int = 0) -> torch.Tensor:
         B = rgb_tokens.shape[0]
         ws_bytes = _lib.lib.ibl_dator_head_workspace_bytes(B)
-        if self._ws is None or self._ws.numel() < ws_bytes:
-            self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(lane)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = self._ws[lane] = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         out = torch.empty((B, 128), dtype=torch.float32, device=self.device)
         st = _lib.lib.ibl_dator_head_forward(C.byref(self.H), rgb_tokens.data_ptr(), depth_tokens.data_ptr(), B, out.data_ptr(),
-                                             self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+                                             ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "ibl_dator_head_forward")
         return out
 
@@ -135,8 +143,16 @@ class DatorEncoder:
         dt = self.depth.forward_patches(self.depth.patches_from_pixels(depth))
         return self.head(rt, dt)
 
-    def embed(self, rgb_crops, depth_crops) -> torch.Tensor:
-        """rgb_crops: list of HxWx3 uint8 (RGB order, no channel swap -- get_embeds.py feeds RGB); depth_crops: list of (h, w) float."""
-        rt = self.rgb.forward_patches(self.rgb.preprocess(rgb_crops))
-        dt = self.depth.forward_patches(self.preprocess_depth(depth_crops))
-        return self.head(rt, dt)
+    def embed(self, rgb_crops, depth_crops=None, lane: int = 0, max_batch: int = 512) -> torch.Tensor:
+        """rgb_crops: list of HxWx3 uint8 (RGB order, no channel swap -- get_embeds.py feeds RGB) or a uint8 tensor (N, H, W, 3);
+        depth_crops: list of (h, w) float or a float32 tensor (N, h, w).  `embed((rgb, depth))` is the form LocaliseEngine calls
+        (its `crops` argument is handed through as is).  lane: workspace index for concurrent forwards on different streams."""
+        if depth_crops is None:
+            rgb_crops, depth_crops = rgb_crops
+        n = rgb_crops.shape[0] if isinstance(rgb_crops, torch.Tensor) else len(rgb_crops)
+        outs = []
+        for i in range(0, n, max_batch):
+            rt = self.rgb.forward_patches(self.rgb.preprocess(rgb_crops[i:i + max_batch]), lane=lane)
+            dt = self.depth.forward_patches(self.preprocess_depth(depth_crops[i:i + max_batch]), lane=lane)
+            outs.append(self.head(rt, dt, lane=lane))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)

@@ -30,8 +30,11 @@ class MemoryShard:
     """Device-resident object memory: all stored embeddings (L2-normalised once),
     per-instance point clouds (x, y, z, intensity) and the spatial hash used by evaluate_transform."""
 
-    def __init__(self, ctx: RegContext, embeddings, clouds, colors=None, intensities=None, eval_threshold=0.02, device="cuda"):
+    def __init__(self, ctx: RegContext, embeddings, clouds=None, colors=None, intensities=None, eval_threshold=0.02, device="cuda",
+                 shard=None):
+        """clouds=None: an embedding-only memory (BASELINE configs[3]: embed + match + assign, nothing to register against)."""
         self.ctx = ctx
+        self.shard = shard
         self.device = torch.device(device)
         counts = [len(e) for e in embeddings]
         self.M = len(counts)
@@ -39,12 +42,14 @@ class MemoryShard:
         raw = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(e, dtype=np.float32) for e in embeddings])))
         self.mem_emb = match.normalize_rows(raw.to(self.device))          # object_memory.py:922
         self.emb_offsets = torch.from_numpy(self.emb_offsets_host).to(self.device)
-        if intensities is None:
-            intensities = [intensity_from_colors(c) for c in colors] if colors is not None else None
-        self.clouds = CloudBatch.from_numpy(clouds, intensities, device=device)
         self.eval_threshold = eval_threshold
-        self.grid = MemGrid(ctx, self.clouds.pts4, cell=2 * eval_threshold)
         self._features = {}
+        self.clouds = self.grid = None
+        if clouds is not None:
+            if intensities is None:
+                intensities = [intensity_from_colors(c) for c in colors] if colors is not None else None
+            self.clouds = CloudBatch.from_numpy(clouds, intensities, device=device)
+            self.grid = MemGrid(ctx, self.clouds.pts4, cell=2 * eval_threshold)
 
     def features(self, voxel_size, local_dist_factor):
         """Normals, FPFH and colour gradients of every memory instance for these registration parameters: computed on first
@@ -62,6 +67,7 @@ class FrameResult:
     assignments: list = field(default_factory=list)
     records: list = field(default_factory=list)
     best: int = -1
+    n_clean: int = 0                      # detected points of the frame left after the radius-outlier removal (:992-998)
 
 
 @dataclass
@@ -157,12 +163,20 @@ class LocaliseEngine:
         disjoint state: the encoder / match workspaces belong to stage A, the registration arena to stage B."""
         dev = self.memory.mem_emb.device
         side = torch.cuda.Stream(device=dev)      # equal priority: raising either stage's stream priority measured 7-8 % slower
-        side.wait_stream(torch.cuda.current_stream(dev))      # inputs (crops, memory) were produced on the caller's stream
+        main = torch.cuda.current_stream(dev)
 
-        def stage_a(b):
+        def stage_a(b, ready):
             torch.cuda.set_device(dev)                      # worker thread: current device and stream are per thread
             with torch.cuda.stream(side):
+                side.wait_event(ready)                      # this batch's inputs (crops) were produced on the caller's stream
                 return self._embed_match(b.get("crops"), b.get("det_emb"))
+
+        def submit(b):
+            # `batches` may be a lazy iterator whose crops are written by kernels on the caller's stream as it is advanced: the
+            # event is recorded when the batch is pulled, and stage A waits for it before touching the crops
+            ready = torch.cuda.Event()
+            ready.record(main)
+            return self._pool_a.submit(stage_a, b, ready)
 
         it = iter(batches)
         cur = next(it, None)
@@ -170,32 +184,45 @@ class LocaliseEngine:
             return
         if self._pool_a is None:
             self._pool_a = ThreadPoolExecutor(max_workers=1)
-        fut = self._pool_a.submit(stage_a, cur)
-        while cur is not None:
-            aug_h = fut.result()
-            nxt = next(it, None)
-            if nxt is not None:
-                fut = self._pool_a.submit(stage_a, nxt)
-            args = dict(kw)
-            for k in ("seed", "job_id_base"):
-                if k in cur:
-                    args[k] = cur[k]
-            yield self.localise_batch(cur["det"], cur["q_per_frame"], aug_h=aug_h, **args)
-            cur = nxt
+        fut = submit(cur)
+        try:
+            while cur is not None:
+                aug_h = fut.result()
+                fut = None
+                nxt = next(it, None)
+                if nxt is not None:
+                    fut = submit(nxt)
+                args = dict(kw)
+                for k in ("seed", "job_id_base"):
+                    if k in cur:
+                        args[k] = cur[k]
+                yield self.localise_batch(cur["det"], cur["q_per_frame"], aug_h=aug_h, **args)
+                cur = nxt
+        finally:
+            # an abandoned generator or a raising batch must not leave stage A running on the side stream with the lane-0 encoder
+            # workspace: a later localise_batch on the caller's stream would race with it
+            if fut is not None:
+                try:
+                    fut.result()
+                except Exception:
+                    pass
+            side.synchronize()
 
     def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
                        fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, outlier_radius=0.05, outlier_nb_points=8,
                        seed=0, job_id_base=0, ransac_max_iter=4000000, num_per_length=4, eval_threshold=None, timings=None,
-                       aug_h=None, _slot=None):
+                       aug_h=None, _slot=None, register=True):
         """det: detected clouds of all frames (segments in frame order, <= 7 per frame); crops: uint8 tensor
         (sum Q, H, W, 3) or list of arrays, or det_emb: (sum Q, D) precomputed embeddings (or aug_h: the host similarity rows
-        stage A of `localise_stream` produced)."""
+        stage A of `localise_stream` produced).  register=False stops after the assignment search (embedding-only memories):
+        the results carry the assignment lists, `best` = 0 and identity poses; `det` may then be None."""
         mem = self.memory
         ctx, pool, lane = (self.ctx, self._pool, 0) if _slot is None else (_slot.ctx, _slot.pool, _slot.lane)
         q_per_frame = np.asarray(q_per_frame, dtype=np.int32)
         F = len(q_per_frame)
         row0 = np.concatenate([[0], np.cumsum(q_per_frame)]).astype(np.int64)
-        assert det.n_seg == int(row0[-1])
+        register = register and mem.clouds is not None
+        assert not register or det.n_seg == int(row0[-1])
         ev = []
 
         def tick(name):
@@ -208,18 +235,20 @@ class LocaliseEngine:
         # ---- embed + match (GPU) -------------------------------------------------------------------
         aug = self._embed_match(crops, det_emb, tick, to_host=False, lane=lane) if aug_h is None else None
         # ---- clean the detected clouds (:992-998) ---------------------------------------------------
-        keep = radius_outlier_batch(ctx, det, outlier_radius, outlier_nb_points)
-        keepb = keep.bool()
-        csum = torch.cumsum(keep.to(torch.int32), 0)
-        csum0 = torch.cat([torch.zeros(1, dtype=torch.int32, device=csum.device), csum])
-        new_off = csum0[det.seg_off.long()]
-        clean_pts = det.pts4[keepb].contiguous()
+        if register:
+            keep = radius_outlier_batch(ctx, det, outlier_radius, outlier_nb_points)
+            keepb = keep.bool()
+            csum = torch.cumsum(keep.to(torch.int32), 0)
+            csum0 = torch.cat([torch.zeros(1, dtype=torch.int32, device=csum.device), csum])
+            new_off = csum0[det.seg_off.long()]
+            clean_pts = det.pts4[keepb].contiguous()
         tick("outlier")
         # ---- one host round trip: fp16 similarity rows + cleaned sizes ------------------------------
         if aug_h is None:
             aug_h = aug.cpu().numpy()
-        new_off_h = new_off.cpu().numpy().astype(np.int32)
-        clean = CloudBatch(clean_pts, new_off_h)
+        if register:
+            new_off_h = new_off.cpu().numpy().astype(np.int32)
+            clean = CloudBatch(clean_pts, new_off_h)
         tick("d2h")
         # ---- assign (host, exact similarity-volume search; :974-982) --------------------------------
         M = mem.M
@@ -234,7 +263,7 @@ class LocaliseEngine:
         # The detections' instance features (normals / FPFH, once per frame batch instead of once per assignment) only need the
         # cleaned clouds, so the GPU computes them while the host cores run the assignment search (both calls release the GIL).
         det_feat_job = None
-        if self.reuse_features:
+        if self.reuse_features and register:
             det_feat_job = pool.submit(self._det_features, clean, fpfh_voxel_size, ctx, torch.cuda.current_stream())
         assns = assign_batch(aug_f, q_emb, num_per_length, self.assign_threads)
         det_feat = det_feat_job.result() if det_feat_job is not None else None
@@ -247,7 +276,15 @@ class LocaliseEngine:
                 job_src.append([int(row0[f]) + d for d, m in a] + [-1] * (3 - len(a)))
                 job_tgt.append([m for d, m in a] + [-1] * (3 - len(a)))
         results = [FrameResult(np.array([0., 0., 0., 0., 0., 0., 1.]), np.array([0., 0., 0., 0., 0., 0., 1.])) for _ in range(F)]
-        if not job_frame:
+        if not register:
+            for f in range(F):
+                results[f].assignments = assns[f]
+                results[f].best = 0 if assns[f] else -1
+        if not job_frame or not register:
+            if timings is not None:
+                torch.cuda.synchronize()
+                for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+                    timings[n1] = timings.get(n1, 0.0) + e0.elapsed_time(e1)
             return results
         J = len(job_frame)
         # instance features: the memory's are resident (built on first use), the detections' were computed above
@@ -294,7 +331,8 @@ class LocaliseEngine:
             last = j0 + n_a - 1
             t_ref = t + means[last, 1] - R @ means[last, 0]                       # stale means of the LAST assignment (:1127)
             t_fix = t + means[j0 + best, 1] - R @ means[j0 + best, 0]
-            results[f] = FrameResult(np.concatenate((t_ref, q)), np.concatenate((t_fix, q)), assns[f], recs, best)
+            results[f] = FrameResult(np.concatenate((t_ref, q)), np.concatenate((t_fix, q)), assns[f], recs, best,
+                                     int(new_off_h[row0[f + 1]] - new_off_h[row0[f]]))
         tick("select")
         if timings is not None:
             torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import ctypes as C
 from . import _lib
 
 GEMM, ATTN, SPFH = 1, 2, 3
-PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F16_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA (same rate), /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
@@ -22,12 +22,12 @@ def read(kid):
 
 
 def roofline(traffic=None):
-    """Roofline object of the dominant kernel family (the bf16 GEMM of the ViT encoder).  `traffic` = HBM bytes per
+    """Roofline object of the dominant kernel family (the fp16 GEMM of the ViT encoder).  `traffic` = HBM bytes per
     launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command (tools/pmc_summary.py)."""
     ms, flops, n = read(GEMM)
     if n == 0 or ms <= 0:
         return None
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "ibl_gemm_bf16_tn", "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "launches": n, "avg_launch_us": ms * 1e3 / n,
+    return {"kernel": "ibl_gemm_f16_tn", "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "launches": n, "avg_launch_us": ms * 1e3 / n,
             "flops_per_launch": flops / n}

@@ -1,7 +1,10 @@
 """Synthetic workload generator: object memories, query frames and ground-truth poses.
 
 No dataset is reachable offline, so parity tests and bench.py draw from this seeded generator:
-  * an object = union of 3-6 random boxes / ellipsoid shells (extent U[0.2, 1.5] m); points are sampled
+  * an object = union of 3-6 random boxes / ellipsoid shells (extent U[0.15, 0.6] m: desk-scale objects, so that
+    5 000 surface points are dense enough -- > 8 neighbours within 5 cm -- to survive the radius-outlier removal
+    localise() applies to every detection; SURVEY §8d's U[0.2, 1.5] m spread 5 000 points so thin that 85 % of every
+    detection was deleted and the registration stage ran on ~700-point sources); points are sampled
     on the surfaces with N(0, (2 mm)^2) noise; colour = 0.5 + 0.5 sin(7 xyz + phi) (smooth, so the
     photometric ICP term is informative);
   * the memory places objects on a jittered grid in the world frame;
@@ -24,12 +27,13 @@ class Primitive:
 
 
 class SynthObject:
-    def __init__(self, rng, world_center):
+    def __init__(self, rng, world_center, extent=(0.15, 0.6)):
         n_prim = int(rng.integers(3, 7))
         self.prims = []
+        spread = 0.4 * extent[1] / 1.5          # primitive centres stay inside the object's largest extent
         for _ in range(n_prim):
-            ext = rng.uniform(0.2, 1.5, size=3)
-            self.prims.append(Primitive(int(rng.integers(0, 2)), rng.uniform(-0.4, 0.4, size=3), ext / 2,
+            ext = rng.uniform(extent[0], extent[1], size=3)
+            self.prims.append(Primitive(int(rng.integers(0, 2)), rng.uniform(-spread, spread, size=3), ext / 2,
                                         Rotation.random(random_state=rng).as_matrix()))
         self.world_center = np.asarray(world_center, dtype=np.float64)
         self.phi = rng.uniform(0, 2 * np.pi, size=3)
@@ -67,7 +71,7 @@ class SynthObject:
 class SynthWorld:
     """M objects on a jittered grid (spacing 2.5 m), E embeddings per instance of dimension D."""
 
-    def __init__(self, M, pts_per_object=5000, E=4, D=768, seed=0, spacing=2.5):
+    def __init__(self, M, pts_per_object=5000, E=4, D=768, seed=0, spacing=2.5, extent=(0.15, 0.6), sample_points=True):
         rng = np.random.default_rng(seed)
         self.rng = rng
         self.M, self.E, self.D = M, E, D
@@ -77,10 +81,10 @@ class SynthWorld:
         for j in range(M):
             gx, gy = j % side, j // side
             c = np.array([gx * spacing, gy * spacing, 0.0]) + np.append(rng.uniform(-0.3, 0.3, size=2), rng.uniform(0.0, 1.0))
-            self.objects.append(SynthObject(rng, c))
+            self.objects.append(SynthObject(rng, c, extent))
         self.points = []
         self.colors = []
-        for o in self.objects:
+        for o in (self.objects if sample_points else []):       # embedding-only memories (BASELINE configs[3]) hold no clouds
             p, c = o.sample(pts_per_object, rng)
             self.points.append(p)
             self.colors.append(c)
@@ -104,7 +108,7 @@ class SynthWorld:
         cand.sort(key=lambda k: (k != j, k))
         return cand[:q]
 
-    def make_frame(self, rng, q=7, pts_per_object=5000, emb_noise=0.1, anchor=None):
+    def make_frame(self, rng, q=7, pts_per_object=5000, emb_noise=0.1, anchor=None, with_clouds=True):
         """Returns dict(ids, clouds (camera frame) list of (pts, cols), det_emb (q, D) fp32, pose T_wc 4x4)."""
         anchor = int(rng.integers(0, self.M)) if anchor is None else anchor
         ids = self.neighbours(anchor, q)
@@ -118,7 +122,7 @@ class SynthWorld:
         T_wc = np.eye(4)
         T_wc[:3, :3], T_wc[:3, 3] = R, t_wc
         clouds = []
-        for k in ids:
+        for k in (ids if with_clouds else []):
             o = self.objects[k]
             frac = rng.uniform(0.6, 0.9)
             pts, col = o.sample(int(pts_per_object / frac * 1.05) + 16, rng)

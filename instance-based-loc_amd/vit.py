@@ -179,8 +179,8 @@ class VitEncoder:
             self._keep.append(t)
             return t.data_ptr()
 
-        def dev_bf16(a):
-            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device).to(torch.bfloat16).contiguous()
+        def dev_f16(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device).to(torch.float16).contiguous()
             self._keep.append(t)
             return t.data_ptr()
 
@@ -188,7 +188,7 @@ class VitEncoder:
         wp = np.zeros((cfg.dim, cfg.patch_k_pad), dtype=np.float32)
         wp[:, :cfg.patch_k] = weights["patch.w"].reshape(cfg.dim, -1)
         W = VitWeights()
-        W.w_patch = dev_bf16(wp)
+        W.w_patch = dev_f16(wp)
         W.b_patch = dev_f32(weights["patch.b"]) if "patch.b" in weights else None
         W.cls_pos = dev_f32(weights["cls"].reshape(-1) + pos[0])
         W.pos_patch = dev_f32(pos[1:])
@@ -197,17 +197,17 @@ class VitEncoder:
         if cfg.final_ln:
             W.ln_f_g, W.ln_f_b = dev_f32(weights["ln_f.g"]), dev_f32(weights["ln_f.b"])
         if cfg.proj_dim:
-            W.w_proj = dev_bf16(weights["proj.w"])
+            W.w_proj = dev_f16(weights["proj.w"])
         for l in range(cfg.depth):
             p = f"l{l}."
             L = W.layers[l]
             L.ln1_g, L.ln1_b = dev_f32(weights[p + "ln1.g"]), dev_f32(weights[p + "ln1.b"])
-            L.w_qkv = dev_bf16(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0))
+            L.w_qkv = dev_f16(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0))
             L.b_qkv = dev_f32(np.concatenate([weights[p + "q.b"], weights[p + "k.b"], weights[p + "v.b"]], axis=0))
-            L.w_o, L.b_o = dev_bf16(weights[p + "o.w"]), dev_f32(weights[p + "o.b"])
+            L.w_o, L.b_o = dev_f16(weights[p + "o.w"]), dev_f32(weights[p + "o.b"])
             L.ln2_g, L.ln2_b = dev_f32(weights[p + "ln2.g"]), dev_f32(weights[p + "ln2.b"])
-            L.w_fc1, L.b_fc1 = dev_bf16(weights[p + "fc1.w"]), dev_f32(weights[p + "fc1.b"])
-            L.w_fc2, L.b_fc2 = dev_bf16(weights[p + "fc2.w"]), dev_f32(weights[p + "fc2.b"])
+            L.w_fc1, L.b_fc1 = dev_f16(weights[p + "fc1.w"]), dev_f32(weights[p + "fc1.b"])
+            L.w_fc2, L.b_fc2 = dev_f16(weights[p + "fc2.w"]), dev_f32(weights[p + "fc2.b"])
             if cfg.layerscale:
                 L.ls1, L.ls2 = dev_f32(weights[p + "ls1"]), dev_f32(weights[p + "ls2"])
         self.W = W
@@ -227,7 +227,7 @@ class VitEncoder:
     # ---- preprocessing -------------------------------------------------------------------------
     def preprocess(self, crops, want_u8=False):
         """crops: list of HxWx3 uint8 numpy arrays (RGB as the detector hands them over), or a single
-        uint8 device/host tensor (N, H, W, 3) of equally sized crops.  Returns bf16 patch matrix (device)."""
+        uint8 device/host tensor (N, H, W, 3) of equally sized crops.  Returns fp16 patch matrix (device)."""
         r = self.recipe
         if isinstance(crops, torch.Tensor):
             n, h, w, _ = crops.shape
@@ -251,7 +251,7 @@ class VitEncoder:
         n = len(shapes)
         P = self.cfg.n_tokens - 1
         tmp = torch.empty(max(tmp_bytes, 16), dtype=torch.uint8, device=self.device)
-        patches = torch.empty((n * P, self.cfg.patch_k_pad), dtype=torch.bfloat16, device=self.device)
+        patches = torch.empty((n * P, self.cfg.patch_k_pad), dtype=torch.float16, device=self.device)
         out_u8 = torch.empty((n, r.out_h, r.out_w, 3), dtype=torch.uint8, device=self.device) if want_u8 else None
         mean = (C.c_float * 3)(*r.mean)
         std = (C.c_float * 3)(*r.std)
@@ -267,7 +267,7 @@ class VitEncoder:
     def forward_patches(self, patches: torch.Tensor, lane: int = 0) -> torch.Tensor:
         """lane: which of the encoder's workspaces to use (concurrent forwards on different streams need their own)."""
         P = self.cfg.n_tokens - 1
-        assert patches.dtype == torch.bfloat16 and patches.is_cuda and patches.shape[1] == self.cfg.patch_k_pad
+        assert patches.dtype == torch.float16 and patches.is_cuda and patches.shape[1] == self.cfg.patch_k_pad
         batch = patches.shape[0] // P
         ws_bytes = _lib.lib.ibl_vit_workspace_bytes(C.byref(self.desc), batch)
         if not hasattr(self, "_ws_lanes"):
@@ -285,7 +285,7 @@ class VitEncoder:
         return out
 
     def patches_from_pixels(self, x: torch.Tensor) -> torch.Tensor:
-        """(B, 3, H, W) float model input (already normalised) -> bf16 patch matrix.  Data-layout plumbing
+        """(B, 3, H, W) float model input (already normalised) -> fp16 patch matrix.  Data-layout plumbing
         only (used by tests and by callers that hold pre-normalised tensors)."""
         cfg = self.cfg
         B = x.shape[0]
@@ -293,8 +293,8 @@ class VitEncoder:
         p = cfg.patch
         t = x.to(self.device, torch.float32).reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5)
         t = t.reshape(B * gh * gw, 3 * p * p)
-        out = torch.zeros((B * gh * gw, cfg.patch_k_pad), dtype=torch.bfloat16, device=self.device)
-        out[:, :cfg.patch_k] = t.to(torch.bfloat16)
+        out = torch.zeros((B * gh * gw, cfg.patch_k_pad), dtype=torch.float16, device=self.device)
+        out[:, :cfg.patch_k] = t.to(torch.float16)
         return out
 
     def embed(self, crops, max_batch=512, streams=1, min_split=128, lane=0) -> torch.Tensor:
@@ -327,29 +327,29 @@ class VitEncoder:
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
 
-LINEAR_BF16, LINEAR_GELU_BF16, LINEAR_RESID_F32, LINEAR_F32 = 0, 1, 2, 4
+LINEAR_F16, LINEAR_GELU_F16, LINEAR_RESID_F32, LINEAR_F32 = 0, 1, 2, 4
 
 
-def linear_bf16(x: torch.Tensor, W: torch.Tensor, bias=None, epilogue=LINEAR_BF16, out=None, scale=None) -> torch.Tensor:
-    """out = epilogue(x W^T + bias) through `ibl_linear_bf16` (the encoder's GEMM kernel on its own).
-    x (rows, n_in) bf16, W (n_out, n_in) bf16 (nn.Linear layout), bias / scale fp32 (n_out).  LINEAR_RESID_F32
+def linear_f16(x: torch.Tensor, W: torch.Tensor, bias=None, epilogue=LINEAR_F16, out=None, scale=None) -> torch.Tensor:
+    """out = epilogue(x W^T + bias) through `ibl_linear_f16` (the encoder's GEMM kernel on its own).
+    x (rows, n_in) fp16, W (n_out, n_in) fp16 (nn.Linear layout), bias / scale fp32 (n_out).  LINEAR_RESID_F32
     accumulates into `out` (fp32), the other epilogues allocate it when it is not given."""
-    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.is_cuda and W.is_cuda
+    assert x.dtype == torch.float16 and W.dtype == torch.float16 and x.is_cuda and W.is_cuda
     assert x.stride(-1) == 1 and W.stride(-1) == 1
     rows, n_in = x.shape
     n_out = W.shape[0]
     if out is None:
         if epilogue == LINEAR_RESID_F32:
             raise ValueError("LINEAR_RESID_F32 accumulates into `out`")
-        out = torch.empty((rows, n_out), device=x.device, dtype=torch.float32 if epilogue == LINEAR_F32 else torch.bfloat16)
-    want = torch.float32 if epilogue in (LINEAR_RESID_F32, LINEAR_F32) else torch.bfloat16
+        out = torch.empty((rows, n_out), device=x.device, dtype=torch.float32 if epilogue == LINEAR_F32 else torch.float16)
+    want = torch.float32 if epilogue in (LINEAR_RESID_F32, LINEAR_F32) else torch.float16
     assert out.dtype == want and out.shape == (rows, n_out) and out.stride(-1) == 1
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == n_out and bias.is_contiguous()
     if scale is not None:
         assert scale.dtype == torch.float32 and scale.numel() == n_out and scale.is_contiguous()
-    st = _lib.lib.ibl_linear_bf16(x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr() if bias is not None else None,
+    st = _lib.lib.ibl_linear_f16(x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr() if bias is not None else None,
                                   scale.data_ptr() if scale is not None else None, rows, n_out, n_in, epilogue, out.data_ptr(),
                                   out.stride(0), torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "ibl_linear_bf16")
+    _lib.check(st, "ibl_linear_f16")
     return out

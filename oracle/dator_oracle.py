@@ -113,3 +113,12 @@ def preprocess_depth(depth_crop: np.ndarray, dmin=0.0, dmax=50.0) -> np.ndarray:
     r = (r - np.float32(dmin)) / np.float32(dmax - dmin)
     r = (r - np.float32(0.5)) / np.float32(0.5)
     return np.repeat(r[None], 3, axis=0).astype(np.float32)
+
+
+def embed(rgb_w, depth_w, head_w, rgb_crops, depth_crops):
+    """RGB crops (HxWx3 u8) + depth crops (h x w float, metres) -> (n, 128): preprocessing of dator/get_embeds.py:80-87,129-136,
+    then build_FourDNet.forward.  Stream weights with the LoRA factors already folded (ibloc_amd.dator.fold_lora)."""
+    from ibloc_amd.dator import STREAM_CFG
+    rgb = np.stack([preprocess_rgb(c) for c in rgb_crops])
+    dep = np.stack([preprocess_depth(c) for c in depth_crops])
+    return forward(rgb_w, depth_w, head_w, STREAM_CFG, rgb, dep)

@@ -1,4 +1,4 @@
-"""-m gpu: DATOR (two TransReID streams on the shared bf16 ViT kernels + fp32 fusion head) vs the torch oracle, which is
+"""-m gpu: DATOR (two TransReID streams on the shared fp16 ViT kernels + fp32 fusion head) vs the torch oracle, which is
 itself pinned to the reference's build_FourDNet (tests/golden/dator_golden.npz)."""
 import os
 
@@ -34,7 +34,7 @@ def test_head_fp32_vs_oracle(enc):
 
 
 def test_full_forward_vs_oracle_and_reference_golden(enc):
-    """pixels -> embedding through the bf16 streams: rel-L2 <= 2e-2, cosine >= 0.9995 (same bar as the other encoders)"""
+    """pixels -> embedding through the fp16 streams: rel-L2 <= 3e-3, cosine >= 0.99999 (same bar as the other encoders)"""
     e, _ = enc
     rng = np.random.default_rng(304)
     rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
@@ -44,7 +44,7 @@ def test_full_forward_vs_oracle_and_reference_golden(enc):
     rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     cos = np.min(np.sum(got * ref, -1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(ref, axis=-1)))
     print("dator rel_l2", rel, "cos", cos)
-    assert rel <= 2e-2 and cos >= 0.9995
+    assert rel <= 3e-3 and cos >= 0.99999
 
 
 def test_preprocess_and_facade(enc):
@@ -58,11 +58,11 @@ def test_preprocess_and_facade(enc):
     pd = e.preprocess_depth(depths)
     exp_px = np.stack([do.preprocess_depth(d) for d in depths])
     exp_p = e.depth.patches_from_pixels(torch.from_numpy(exp_px)).float().cpu().numpy()
-    assert np.abs(pd.float().cpu().numpy() - exp_p).max() <= 2 ** -7        # one bf16 step at |x| <= 1
+    assert np.abs(pd.float().cpu().numpy() - exp_p).max() <= 2 ** -11       # half an fp16 step at |x| <= 1
     got = e.embed(crops, depths).cpu().numpy()
     exp = do.forward(rw, dw, hw, D.STREAM_CFG, np.stack([do.preprocess_rgb(c) for c in crops]), exp_px)
     rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
-    assert rel <= 2e-2
+    assert rel <= 3e-3
     # the reference-shaped entry point: bbox crop of the full depth image
     emb.set_encoder("dator", e)
     full_depth = rng.uniform(0.3, 8.0, size=(200, 240)).astype(np.float32)
@@ -71,4 +71,4 @@ def test_preprocess_and_facade(enc):
                                    device="cuda")
     assert out.shape == (128,)
     exp1 = do.forward(rw, dw, hw, D.STREAM_CFG, do.preprocess_rgb(crops[0])[None], do.preprocess_depth(full_depth[30:150, 20:110])[None])[0]
-    assert np.linalg.norm(out.cpu().numpy() - exp1) / np.linalg.norm(exp1) <= 2e-2
+    assert np.linalg.norm(out.cpu().numpy() - exp1) / np.linalg.norm(exp1) <= 3e-3

@@ -56,7 +56,7 @@ def test_embeddings_facade():
     assert isinstance(out, torch.Tensor) and out.dim() == 1 and out.shape[0] == cfg.dim
     exp = vo.embed_crops(w, cfg, pp.RECIPES["dinov2"], [crop])[0]
     got = np.array(out.cpu())
-    assert np.linalg.norm(got - exp) / np.linalg.norm(exp) < 2e-2
+    assert np.linalg.norm(got - exp) / np.linalg.norm(exp) < 3e-3
     ccfg = V.CONFIGS["tiny_clip"]
     cw = V.random_weights(ccfg, 3)
     emb.set_encoder("clip", V.VitEncoder(ccfg, cw))

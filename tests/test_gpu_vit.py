@@ -1,8 +1,8 @@
-"""-m gpu: crop preprocessing (bit-exact u8 vs PIL) and the bf16-MFMA ViT forward vs the fp32 oracle.
+"""-m gpu: crop preprocessing (bit-exact u8 vs PIL) and the fp16-MFMA ViT forward vs the fp32 oracle.
 
-Tolerance for the forward: the HIP path multiplies in bf16 (8-bit mantissa) with fp32 accumulation and
-keeps the residual stream in fp32; against the fp32 oracle the CLS embedding must agree to
-rel-L2 <= 2e-2 and cosine >= 0.9995 (measured ~5e-3 / 0.99999 on the 12-layer ViT-B/14)."""
+Tolerance for the forward: the HIP path multiplies fp16 operands (11-bit significand) with fp32 accumulation and keeps the
+residual stream in fp32; against the fp32 oracle the CLS embedding must agree to rel-L2 <= 3e-3 (2x the measured error of the
+12-layer ViT-B/14, see DESIGN (c); bf16 operands gave 1.1e-2) and cosine >= 0.99999."""
 import os
 
 import numpy as np
@@ -43,7 +43,7 @@ def test_preprocess_u8_bit_exact_vs_pil(recipe_name, cfg_name):
     for i, c in enumerate(crops):
         exp = vo.preprocess_crop_u8(c, r)
         assert np.array_equal(u8[i], exp), f"crop {i} {shapes[i]}"
-    # the normalised bf16 patch matrix against the oracle's float model input
+    # the normalised fp16 patch matrix against the oracle's float model input
     px = np.stack([vo.preprocess_crop(c, r) for c in crops])
     exp_p = enc.patches_from_pixels(torch.from_numpy(px)).float().cpu().numpy()
     got_p = patches.float().cpu().numpy()
@@ -61,7 +61,7 @@ def test_forward_vs_oracle(case):
     r, c = rel_l2(got, exp), cosine(got, exp)
     print(f"{key}: rel_l2={r:.3e} cos={c:.6f}")
     assert np.isfinite(got).all()
-    assert r <= 2e-2 and c >= 0.9995
+    assert r <= 3e-3 and c >= 0.99999
 
 
 def test_forward_batch_sizes_and_determinism():
@@ -79,7 +79,7 @@ def test_forward_batch_sizes_and_determinism():
     one = enc.forward_patches(p[:P].contiguous()).cpu().numpy()
     assert np.array_equal(one[0], full[0])          # batch-invariant: each crop is computed independently
     exp = vo.vit_forward(w, cfg, x)
-    assert rel_l2(full, exp) <= 2e-2
+    assert rel_l2(full, exp) <= 3e-3
 
 
 def test_embed_crops_end_to_end():
@@ -92,7 +92,7 @@ def test_embed_crops_end_to_end():
     crops = [rng.integers(0, 256, size=(h, wd, 3), dtype=np.uint8) for h, wd in [(90, 120), (224, 224), (300, 200)]]
     got = enc.embed(crops).cpu().numpy()
     exp = vo.embed_crops(w, cfg, pp.RECIPES["dinov2"], crops)
-    assert rel_l2(got, exp) <= 2e-2 and cosine(got, exp) >= 0.9995
+    assert rel_l2(got, exp) <= 3e-3 and cosine(got, exp) >= 0.99999
 
 
 def test_embed_micro_batches_on_two_streams_equal_one_stream():

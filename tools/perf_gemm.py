@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Microbenchmark of ibl_linear_bf16 on the four ViT-B/14 layer shapes (224 crops x 257 tokens)."""
+"""Microbenchmark of ibl_linear_f16 on the four ViT-B/14 layer shapes (224 crops x 257 tokens)."""
 import ctypes
 import os
 import sys
@@ -19,17 +19,17 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 224 * 257
 shapes = [("qkv", 2304, 768, 0), ("proj", 768, 768, 2), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)]
 tot_ms, tot_fl = 0.0, 0.0
 for name, n_out, n_in, epi in shapes:
-    x = torch.randn(rows, n_in, device="cuda").to(torch.bfloat16)
-    W = (torch.randn(n_out, n_in, device="cuda") / n_in ** 0.5).to(torch.bfloat16)
+    x = torch.randn(rows, n_in, device="cuda").to(torch.float16)
+    W = (torch.randn(n_out, n_in, device="cuda") / n_in ** 0.5).to(torch.float16)
     b = torch.randn(n_out, device="cuda")
-    out = torch.zeros(rows, n_out, device="cuda", dtype=torch.float32 if epi == 2 else torch.bfloat16)
+    out = torch.zeros(rows, n_out, device="cuda", dtype=torch.float32 if epi == 2 else torch.float16)
     for _ in range(3):
-        V.linear_bf16(x, W, b, epi, out=out)
+        V.linear_f16(x, W, b, epi, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 20
     e0.record()
     for _ in range(n):
-        V.linear_bf16(x, W, b, epi, out=out)
+        V.linear_f16(x, W, b, epi, out=out)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n

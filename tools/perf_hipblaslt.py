@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Calibration only (not product code): what the vendor library reaches on the four ViT-B/14 GEMM shapes (plain bf16 GEMM,
-no fused epilogue), to tell a practical ceiling of this board from headroom in ibl_gemm_bf16_tn."""
+no fused epilogue), to tell a practical ceiling of this board from headroom in ibl_gemm_f16_tn."""
 import sys
 import torch
 

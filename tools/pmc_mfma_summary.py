@@ -26,7 +26,7 @@ for i in ids:
     if i < last:
         continue
     k = names[i]
-    key = "ibl_gemm_bf16_tn (all epilogues)" if "ibl_gemm_bf16_tn" in k else k
+    key = "ibl_gemm_f16_tn (all epilogues)" if "ibl_gemm_f16_tn" in k else k
     for c, v in rows[i].items():
         fam[key][c] += v
     fam[key]["launches"] += 1

@@ -41,7 +41,7 @@ def main():
     gemm_launches = int(sys.argv[4]) if len(sys.argv) > 4 else 50     # 11 layers x 4 + the CLS-only last layer x 5 + patch embedding, one 224-crop batch
     out = {}
     for tag, rows, scale in (("fetch", fetch, 1024.0 * 2.0), ("write", write, 1024.0)):
-        g = [(i, k, v) for i, k, v, _ in rows if "ibl_gemm_bf16_tn" in k]
+        g = [(i, k, v) for i, k, v, _ in rows if "ibl_gemm_f16_tn" in k]
         g = g[-gemm_launches:]
         out[f"gemm_{tag}_bytes_per_launch"] = sum(v for _, _, v in g) * scale / max(1, len(g))
         out[f"gemm_{tag}_launches"] = len(g)
