@@ -74,6 +74,12 @@ _SIGS = {
     "ibl_dator_head_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),
     "ibl_preprocess_depth": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
     "ibl_assign_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int]),
+    "ibl_assign_candidates": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
+                                        C.c_int, C.c_int]),
+    "ibl_topk_select": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "ibl_match_topk_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "ibl_match_topk": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp,
+                                 C.c_int64, vp]),
 }
 
 

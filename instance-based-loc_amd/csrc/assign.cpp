@@ -415,16 +415,50 @@ inline bool same_assn(const Assn& x, const Assn& y) {
     return true;
 }
 
-// one frame; aug is [Q][M+1] half bits
-static int assign_frame(const uint16_t* aug, int Q, int M, int npl, int32_t* out_assn, int32_t* out_len,
-                        int max_assn) {
+// Proof obligations of a search that ran on per-row candidate columns only (ibl_assign_candidates): every dropped entry of row i has a
+// value in [lo[i], hi[i]]; rmin / rmax are the row's true extremes.  A sub-volume's result is that of the full search when its k-th
+// best value T exceeds (a) every value a cell with a dropped coordinate could take -- the chained fp16 product is monotone in each
+// coordinate, so its maximum over the box [lo, hi] x (row ranges of the other coordinates) is attained at a corner -- and (b) zero,
+// the value of the cells that touch a column another row contributed (those entries are filled with 0, see ibl_assign_candidates).
+struct Verify {
+    const float* lo; const float* hi; const float* rmin; const float* rmax;
+    const uint8_t* complete;      // row has every column: nothing was dropped
+    bool any_holes;               // some row lacks a column another row contributed
+    bool exact;
+};
+
+static bool subvolume_proved(const Verify& vf, const int* chosen, int dim, float T) {
+    bool all_complete = true;
+    for (int d = 0; d < dim; ++d) all_complete = all_complete && vf.complete[chosen[d]];
+    if (all_complete && !vf.any_holes) return true;
+    if (!(T > NEG_INF)) return false;
+    if (vf.any_holes && !(T > 0.0f)) return false;
+    float lo[3], hi[3];
+    for (int d = 0; d < dim; ++d) {
+        lo[d] = vf.rmin[chosen[d]];
+        hi[d] = vf.rmax[chosen[d]];
+        if (d > 0) { lo[d] = std::min(lo[d], 1.0f); hi[d] = std::max(hi[d], 1.0f); }     // coordinates 1, 2 may be unassigned (1.0)
+    }
+    for (int t = 0; t < dim; ++t) {
+        if (vf.complete[chosen[t]]) continue;
+        float a[3][2];
+        for (int d = 0; d < dim; ++d) { a[d][0] = lo[d]; a[d][1] = hi[d]; }
+        a[t][0] = vf.lo[chosen[t]];
+        a[t][1] = vf.hi[chosen[t]];
+        for (int c = 0; c < (1 << dim); ++c) {
+            float f = hmul(a[0][c & 1], a[1][(c >> 1) & 1]);
+            if (dim == 3) f = hmul(f, a[2][(c >> 2) & 1]);
+            if (!(f < T)) return false;            // also catches NaN
+        }
+    }
+    return true;
+}
+
+// one frame; rows is [Q][M+1] floats holding half-representable values; colmap (or null) renames the M assigned columns in the output
+static int assign_rows(const std::vector<float>& rows, int Q, int M, int npl, int32_t* out_assn, int32_t* out_len, int max_assn,
+                       Verify* vf, const int32_t* colmap) {
     if (Q <= 0) return 0;
     const int k = npl * Q * 4;
-    // per-thread scratch, reused across frames (fresh large allocations per frame serialise threads in mmap)
-    static thread_local std::vector<float> rows;
-    rows.resize((size_t)Q * (M + 1));
-    for (int i = 0; i < Q; ++i)
-        for (int j = 0; j <= M; ++j) rows[(size_t)i * (M + 1) + j] = half_bits_to_float(aug[(size_t)i * (M + 1) + j]);
 
     static thread_local std::vector<Assn> uniq;     // first occurrences, in order
     static thread_local std::vector<int> table;     // open-addressing index over `uniq` (<= 35*k entries)
@@ -472,6 +506,7 @@ static int assign_frame(const uint16_t* aug, int Q, int M, int npl, int32_t* out
         std::partial_sort(cells.begin(), cells.begin() + take, cells.end(), cell_before);
         cells.resize(take);
         while ((int)cells.size() < k) cells.push_back({NEG_INF, 0});
+        if (vf && !vf->complete[0] && !(cells[k - 1].v > vf->hi[0])) vf->exact = false;   // 1-D: the score is the entry itself
         for (const auto& c : cells) {
             if ((int)c.flat == M) continue;    // unassigned index
             Assn a; a.len = 1; a.pair[0][0] = 0; a.pair[0][1] = (int32_t)c.flat; a.cost = c.v;
@@ -523,6 +558,7 @@ static int assign_frame(const uint16_t* aug, int Q, int M, int npl, int32_t* out
                     s.s0 = &sorted[chosen[0]]; s.s1 = &sorted[chosen[1]];
                     s.s2 = dim == 3 ? &sorted[chosen[2]] : nullptr;
                     s.run(cells);
+                    if (vf && vf->exact && !subvolume_proved(*vf, chosen, dim, cells.empty() ? NEG_INF : cells.back().v)) vf->exact = false;
                     for (const auto& c : cells) {
                         int ind[3];
                         int64_t fl = c.flat;
@@ -554,7 +590,7 @@ static int assign_frame(const uint16_t* aug, int Q, int M, int npl, int32_t* out
             out_len[n_out] = sel[i]->len;
             for (int p = 0; p < 3; ++p) {
                 out_assn[(n_out * 3 + p) * 2 + 0] = p < sel[i]->len ? sel[i]->pair[p][0] : -1;
-                out_assn[(n_out * 3 + p) * 2 + 1] = p < sel[i]->len ? sel[i]->pair[p][1] : -1;
+                out_assn[(n_out * 3 + p) * 2 + 1] = p < sel[i]->len ? (colmap ? colmap[sel[i]->pair[p][1]] : sel[i]->pair[p][1]) : -1;
             }
             ++n_out;
         }
@@ -562,7 +598,118 @@ static int assign_frame(const uint16_t* aug, int Q, int M, int npl, int32_t* out
     return n_out;
 }
 
+static int assign_frame(const uint16_t* aug, int Q, int M, int npl, int32_t* out_assn, int32_t* out_len, int max_assn) {
+    // per-thread scratch, reused across frames (fresh large allocations per frame serialise threads in mmap)
+    static thread_local std::vector<float> rows;
+    rows.resize((size_t)std::max(Q, 0) * (M + 1));
+    for (int i = 0; i < Q; ++i)
+        for (int j = 0; j <= M; ++j) rows[(size_t)i * (M + 1) + j] = half_bits_to_float(aug[(size_t)i * (M + 1) + j]);
+    return assign_rows(rows, Q, M, npl, out_assn, out_len, max_assn, nullptr, nullptr);
+}
+
+// One frame of ibl_assign_candidates: per row n entries (value bits, global column), the union over the memory shards of each
+// shard's k_hi largest and k_lo smallest entries under (value, lower column first).
+static int assign_frame_candidates(const uint16_t* val, const int32_t* idx, const int32_t* cnt, int64_t stride, int Q, int M_total, int k_hi,
+                                   int k_lo, int npl, int32_t* out_assn, int32_t* out_len, int max_assn, uint8_t* out_exact) {
+    struct Ent { float v; int32_t c; };
+    static thread_local std::vector<Ent> ents, keep[7];
+    static thread_local std::vector<int32_t> U;
+    static thread_local std::vector<float> rows;
+    float lo[7], hi[7], rmin[7], rmax[7];
+    uint8_t complete[7];
+    U.clear();
+    for (int i = 0; i < Q; ++i) {
+        const int n = cnt[i];
+        ents.resize(n);
+        for (int e = 0; e < n; ++e) ents[e] = {half_bits_to_float(val[i * stride + e]), idx[i * stride + e]};
+        auto desc = [](const Ent& x, const Ent& y) { return x.v != y.v ? x.v > y.v : x.c < y.c; };
+        auto asc = [](const Ent& x, const Ent& y) { return x.v != y.v ? x.v < y.v : x.c < y.c; };
+        keep[i].clear();
+        complete[i] = n >= M_total || n == 0;        // (an empty list can only belong to an empty memory)
+        if (complete[i] || n <= k_hi + k_lo) {
+            // every column of the row (or a single shard's whole list): nothing to merge
+            keep[i] = ents;
+            lo[i] = hi[i] = 0.0f;
+            if (!complete[i]) {                                   // a single producer's list: its own k_hi-th / k_lo-th entries bound the rest
+                std::sort(ents.begin(), ents.end(), desc);
+                hi[i] = ents[std::min(n, k_hi) - 1].v;
+                lo[i] = k_lo > 0 ? ents[n - std::min(n, k_lo)].v : -std::numeric_limits<float>::infinity();
+            }
+        } else {
+            std::partial_sort(ents.begin(), ents.begin() + k_hi, ents.end(), desc);
+            keep[i].assign(ents.begin(), ents.begin() + k_hi);
+            hi[i] = ents[k_hi - 1].v;
+            // the low end among the remaining entries (an entry is never taken twice)
+            std::partial_sort(ents.begin() + k_hi, ents.begin() + k_hi + k_lo, ents.end(), asc);
+            keep[i].insert(keep[i].end(), ents.begin() + k_hi, ents.begin() + k_hi + k_lo);
+            lo[i] = k_lo > 0 ? ents[k_hi + k_lo - 1].v : -std::numeric_limits<float>::infinity();
+        }
+        rmin[i] = std::numeric_limits<float>::infinity();
+        rmax[i] = -rmin[i];
+        for (const auto& e : keep[i]) { rmin[i] = std::min(rmin[i], e.v); rmax[i] = std::max(rmax[i], e.v); U.push_back(e.c); }
+        if (keep[i].empty()) { rmin[i] = rmax[i] = 0.0f; }
+    }
+    std::sort(U.begin(), U.end());
+    U.erase(std::unique(U.begin(), U.end()), U.end());
+    const int Mp = (int)U.size();
+    rows.assign((size_t)Q * (Mp + 1), 0.0f);
+    bool holes = false;
+    for (int i = 0; i < Q; ++i) {
+        float* r = &rows[(size_t)i * (Mp + 1)];
+        r[Mp] = 1.0f;
+        for (const auto& e : keep[i]) r[std::lower_bound(U.begin(), U.end(), e.c) - U.begin()] = e.v;
+        holes = holes || (int)keep[i].size() < Mp;
+    }
+    Verify vf{lo, hi, rmin, rmax, complete, holes, true};
+    const int n = assign_rows(rows, Q, Mp, npl, out_assn, out_len, max_assn, &vf, U.data());
+    *out_exact = vf.exact ? 1 : 0;
+    return n;
+}
+
 }  // namespace
+
+extern "C" int ibl_assign_candidates(const uint16_t* cand_val, const int32_t* cand_idx, const int32_t* cand_cnt, int64_t cand_stride,
+                                     const int32_t* row_first, const int32_t* q_per_frame, int n_frames, int M_total, int k_hi, int k_lo,
+                                     int num_per_length, int32_t* out_assn, int32_t* out_len, int32_t* out_count, uint8_t* out_exact,
+                                     int max_assn, int n_threads) {
+    if (!cand_val || !cand_idx || !cand_cnt || !row_first || !q_per_frame || !out_assn || !out_len || !out_count || !out_exact)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_assign_candidates: null pointer");
+    if (n_frames < 0 || M_total < 0 || num_per_length <= 0 || max_assn < 6 || k_hi <= 0 || k_lo < 0 || cand_stride <= 0)
+        return ibl_set_error(IBL_ERR_ARG, "ibl_assign_candidates: bad sizes (max_assn must be >= 6)");
+    for (int f = 0; f < n_frames; ++f) {
+        if (q_per_frame[f] < 0 || q_per_frame[f] > 7) return ibl_set_error(IBL_ERR_ARG, "ibl_assign_candidates: q_per_frame out of range");
+        for (int i = 0; i < q_per_frame[f]; ++i) {
+            const int c = cand_cnt[row_first[f] + i];
+            if (c < 0 || c > cand_stride) return ibl_set_error(IBL_ERR_ARG, "ibl_assign_candidates: candidate count out of range");
+        }
+    }
+    std::vector<int> status(n_frames, 0);
+    auto work = [&](int f0, int f1) {
+        for (int f = f0; f < f1; ++f) {
+            const int64_t r0 = row_first[f];
+            int n = assign_frame_candidates(cand_val + r0 * cand_stride, cand_idx + r0 * cand_stride, cand_cnt + r0, cand_stride,
+                                            q_per_frame[f], M_total, k_hi, k_lo, num_per_length, out_assn + (size_t)f * max_assn * 6,
+                                            out_len + (size_t)f * max_assn, max_assn, out_exact + f);
+            status[f] = n;
+            out_count[f] = n < 0 ? 0 : n;
+        }
+    };
+    int nt = std::max(1, std::min(n_threads, n_frames));
+    if (nt == 1) {
+        work(0, n_frames);
+    } else {
+        std::vector<std::thread> th;
+        int per = (n_frames + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) {
+            int f0 = t * per, f1 = std::min(n_frames, f0 + per);
+            if (f0 < f1) th.emplace_back(work, f0, f1);
+        }
+        for (auto& t : th) t.join();
+    }
+    for (int f = 0; f < n_frames; ++f)
+        if (status[f] < 0) return ibl_set_error(IBL_ERR_INTERNAL, "ibl_assign_candidates: output overflow");
+    return IBL_OK;
+}
 
 extern "C" int ibl_assign_batch(const uint16_t* aug_half, const int32_t* q_per_frame, int n_frames, int q_stride,
                                 int M, int num_per_length, int32_t* out_assn, int32_t* out_len,

@@ -3,10 +3,21 @@ frames at once.  This is the MI355X restatement of the body of ObjectMemory.loca
 (/root/reference/object_memory/object_memory.py:911-1131); the per-frame facade with the reference's
 signature lives in object_memory/object_memory.py.
 
-Everything numerical runs in libibloc_hip.so; torch is used for device memory, stream handling and
+Two stages per batch of frames:
+  A  embed the crops, match them against the memory embeddings on the device, keep per query row the two-ended candidate list
+     (csrc/topk.hip), bring the candidates to the host (1.3 KB per row instead of the 2 (M + 1)-byte row) and run the exact
+     similarity-volume search on them (csrc/assign.cpp; proved equal to the search on full rows, else redone on the full rows).
+     With the embedding memory sharded over ranks (MemoryShard(shard=(rank, world))) the query rows and the per-shard candidate
+     lists are all-gathered over RCCL here (parallel.ShardExchange) -- every collective of a step is issued by this stage.
+  B  clean the detected clouds, compute their features, register every candidate assignment against the (resident) memory clouds,
+     evaluate against the whole memory, select and assemble the pose.
+`localise_stream` runs stage A of batch k + 1 on a second HIP stream / host thread while stage B of batch k executes.
+
+Everything numerical runs in libibloc_hip.so; torch is used for device memory, stream handling, `torch.distributed` and
 order-preserving boolean compaction only.
 """
 import os
+import warnings
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 
@@ -15,9 +26,12 @@ import torch
 from scipy.spatial.transform import Rotation
 
 from . import match
-from .assign import assign_batch
+from .assign import K_HI, K_LO, assign_batch, assign_candidates
+from .parallel import ShardExchange, merge_lists_host, shard_range
 from .registration import (CloudBatch, MemGrid, RegContext, evaluate_batch, instance_features_batch, radius_outlier_batch,
                            register_batch)
+
+IBL_ST_GRID_OVERFLOW = 1          # ibl_reg_ctx_status bits (include/ibloc.h)
 
 
 def intensity_from_colors(colors) -> np.ndarray:
@@ -27,20 +41,29 @@ def intensity_from_colors(colors) -> np.ndarray:
 
 
 class MemoryShard:
-    """Device-resident object memory: all stored embeddings (L2-normalised once),
-    per-instance point clouds (x, y, z, intensity) and the spatial hash used by evaluate_transform."""
+    """Device-resident object memory: the stored embeddings (L2-normalised once), per-instance point clouds
+    (x, y, z, intensity) and the spatial hash used by evaluate_transform.
+
+    clouds=None: an embedding-only memory (BASELINE configs[3]: embed + match + assign, nothing to register against).
+    shard=(rank, world): this rank keeps the embeddings of the instances [lo, hi) = parallel.shard_range(M, rank, world) only
+    (clouds, when given, stay replicated); instance indices everywhere else remain global."""
 
     def __init__(self, ctx: RegContext, embeddings, clouds=None, colors=None, intensities=None, eval_threshold=0.02, device="cuda",
                  shard=None):
-        """clouds=None: an embedding-only memory (BASELINE configs[3]: embed + match + assign, nothing to register against)."""
         self.ctx = ctx
-        self.shard = shard
         self.device = torch.device(device)
-        counts = [len(e) for e in embeddings]
-        self.M = len(counts)
+        self.M = len(embeddings)
+        self.shard = shard
+        self.lo, self.hi = shard_range(self.M, *shard) if shard is not None else (0, self.M)
+        own = embeddings[self.lo:self.hi]
+        counts = [len(e) for e in own]
         self.emb_offsets_host = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        raw = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(e, dtype=np.float32) for e in embeddings])))
-        self.mem_emb = match.normalize_rows(raw.to(self.device))          # object_memory.py:922
+        dim = np.asarray(embeddings[0]).shape[-1] if self.M else 0
+        raw = np.concatenate([np.asarray(e, dtype=np.float32) for e in own]) if len(own) else np.zeros((0, dim), np.float32)
+        if len(raw):
+            self.mem_emb = match.normalize_rows(torch.from_numpy(np.ascontiguousarray(raw)).to(self.device))     # object_memory.py:922
+        else:
+            self.mem_emb = torch.zeros((0, dim), dtype=torch.float32, device=self.device)
         self.emb_offsets = torch.from_numpy(self.emb_offsets_host).to(self.device)
         self.eval_threshold = eval_threshold
         self._features = {}
@@ -53,11 +76,18 @@ class MemoryShard:
 
     def features(self, voxel_size, local_dist_factor):
         """Normals, FPFH and colour gradients of every memory instance for these registration parameters: computed on first
-        use, then resident in HBM (820 MB per 1 000 instances of 5 000 points) for every later query."""
+        use, then resident in HBM (1.8 GB per 1 000 instances of 5 000 points) for every later query."""
         key = (float(voxel_size), float(local_dist_factor))
         if key not in self._features:
             self._features[key] = instance_features_batch(self.ctx, self.clouds, voxel_size, 2.0 * (voxel_size * local_dist_factor))
         return self._features[key]
+
+    def close(self):
+        """Frees the host side of the spatial hash (the device side lives in the context arena)."""
+        if self.grid is not None:
+            self.grid.close()
+            self.grid = None
+        self._features = {}
 
 
 @dataclass
@@ -73,31 +103,58 @@ class FrameResult:
 @dataclass
 class _Lane:
     ctx: RegContext                       # scratch arena of this lane's registration calls
-    pool: ThreadPoolExecutor              # its detections'-features worker
     lane: int                             # encoder workspace index
     stream: "torch.cuda.Stream"
 
 
 class LocaliseEngine:
-    def __init__(self, memory: MemoryShard, encoder=None, assign_threads=0):
+    def __init__(self, memory: MemoryShard, encoder=None, assign_threads=0, k_hi=K_HI, k_lo=K_LO, group=None, rows_cap=224):
         self.memory = memory
         self.encoder = encoder
         self.ctx = memory.ctx
         self.assign_threads = assign_threads or min(os.cpu_count() or 1, 16)
+        self.k_hi, self.k_lo = int(k_hi), int(k_lo)
         self.reuse_features = True      # False: every assignment recomputes its features (same results, the reference's schedule)
-        self._pool = ThreadPoolExecutor(max_workers=1)
+        self.use_candidates = True      # False: the assignment search always runs on the full rows (what round 1 did)
         self._pool_a = None             # stage-A worker of localise_stream
         self._pool_w = None             # lane threads of localise_concurrent
         self._lanes = []
+        self.exchange = ShardExchange(group, rows_cap) if memory.shard is not None and memory.shard[1] > 1 else None
+        self.stats = {"frames": 0, "fallback_frames": 0}        # how often the candidate search had to be redone on full rows
 
-    def _det_features(self, clean, voxel_size, ctx, stream):
-        torch.cuda.set_device(clean.pts4.device)          # worker thread: the current device and stream are per thread
-        with torch.cuda.stream(stream):
-            return instance_features_batch(ctx, clean, voxel_size)
+    def close(self):
+        """Releases the lane arenas (multi-GB hipMalloc each) and worker threads now instead of at garbage collection."""
+        for lane in self._lanes:
+            lane.ctx.close()
+        self._lanes = []
+        for p in (self._pool_a, self._pool_w):
+            if p is not None:
+                p.shutdown(wait=True)
+        self._pool_a = self._pool_w = None
 
-    def _embed_match(self, crops, det_emb, tick=lambda name: None, to_host=True, lane=0):
-        """Stage A: embed + match on the current stream -> fp16 similarity rows (one row per detection, M + 1 columns)."""
+    def check_status(self):
+        """Reads (and clears) the registration context's device status word; warns when a scratch grid overflowed its cell budget
+        (the neighbourhood search then took the slow path: results unaffected, time is)."""
+        st = self.ctx.status()
+        if st & IBL_ST_GRID_OVERFLOW:
+            warnings.warn("registration scratch grid overflowed its cell budget: a neighbourhood search fell back to the slow path "
+                          "(results unaffected); clouds this large want a larger arena or a coarser fpfh_voxel_size")
+        return st
+
+    # ---- stage A ---------------------------------------------------------------------------------------------------------
+    def match_assign(self, q_per_frame, crops=None, det_emb=None, num_per_length=4, lane=0, tick=lambda name: None):
+        """Stage A: embed + match + candidate selection on the current stream, assignment search on the host.  Returns the list
+        (one entry per frame) of assignment lists `[[det_idx, mem_idx], ...]` with GLOBAL memory indices -- what the reference's
+        SimVolume(closest_similarities).get_top_indices_from_subvolumes(4) returns (object_memory.py:974-982)."""
         mem = self.memory
+        q_per_frame = np.asarray(q_per_frame, dtype=np.int32)
+        F = len(q_per_frame)
+        if (q_per_frame > 7).any():
+            raise ValueError("more than 7 detections in a frame: select the 7 largest first (object_memory.py:900-908)")
+        q_emb = np.minimum(q_per_frame, mem.M).astype(np.int32)      # Q > M truncates the detections that are matched (:918-920)
+        if (q_emb < np.minimum(q_per_frame, 3)).any():
+            raise AssertionError("fewer memory objects than the sub-volume dimension (reference asserts at similarity_volume.py:112)")
+        row0 = np.concatenate([[0], np.cumsum(q_per_frame)]).astype(np.int32)
         if det_emb is None:
             if self.encoder is None:
                 raise ValueError("no encoder: pass det_emb")
@@ -105,12 +162,64 @@ class LocaliseEngine:
         else:
             det_emb = torch.as_tensor(det_emb, dtype=torch.float32, device=mem.device).contiguous()
         tick("embed")
-        # Q > M truncates the detections that are matched (object_memory.py:918-920)
         detn = match.normalize_rows(det_emb)                                        # :924
-        _, aug = match.closest_similarity(detn, mem.mem_emb, mem.emb_offsets, want_sims=False, want_aug=True)   # :933-936, sim_volume :13-18
-        tick("match")
-        return aug.cpu().numpy() if to_host else aug
+        R = detn.shape[0]
+        ex = self.exchange
+        if ex is None:
+            val, idx, cnt, aug = match.match_topk(detn, mem.mem_emb, mem.emb_offsets, self.k_hi, self.k_lo, 0)   # :933-936 + sim_volume :13-18
+            tick("match")
+            if not self.use_candidates:
+                aug_h = aug.cpu().numpy()
+                tick("d2h")
+                return self._assign_full(aug_h, row0, q_emb, num_per_length, tick)
+            val_h, idx_h = val.cpu().numpy(), idx.cpu().numpy()
+            cnt_h = cnt.cpu().numpy().sum(axis=1).astype(np.int32)
+        else:
+            allq = ex.gather_queries(detn)                                          # (W * cap, D)
+            val, idx, cnt, aug = match.match_topk(allq, mem.mem_emb, mem.emb_offsets, self.k_hi, self.k_lo, mem.lo)
+            tick("match")
+            gv, gi, gc = ex.gather_candidates(val, idx, cnt)                        # (W, cap, S) lists of this rank's rows
+            val_h, idx_h, cnt_h = merge_lists_host(gv[:, :R].cpu().numpy(), gi[:, :R].cpu().numpy(), gc[:, :R].cpu().numpy())
+        tick("d2h")
+        assns, exact = assign_candidates(val_h, idx_h, cnt_h, row0[:-1], q_emb, mem.M, self.k_hi, self.k_lo, num_per_length,
+                                         self.assign_threads)
+        redo = np.nonzero(~exact)[0]
+        self.stats["frames"] += F
+        self.stats["fallback_frames"] += len(redo)
+        if ex is not None:
+            if ex.any_flag(len(redo) > 0, detn.device):                             # rare: some rank could not prove a frame
+                full = ex.gather_blocks(aug, mem.M)[:R]
+                if len(redo):
+                    self._redo_full(full, redo, row0, q_emb, num_per_length, assns)
+        elif len(redo):
+            self._redo_full(aug, redo, row0, q_emb, num_per_length, assns)
+        tick("assign")
+        return assns
 
+    def _redo_full(self, aug_dev, frames, row0, q_emb, num_per_length, assns):
+        """the exact search on the full rows of the frames whose candidate search could not be proved (ties at the threshold)"""
+        rows = np.concatenate([np.arange(row0[f], row0[f] + q_emb[f]) for f in frames])
+        sub = aug_dev[torch.from_numpy(rows).to(aug_dev.device)].cpu().numpy()
+        M = aug_dev.shape[1] - 1
+        aug_f = np.ones((len(frames), 7, M + 1), dtype=np.float16)
+        o = 0
+        for i, f in enumerate(frames):
+            aug_f[i, :q_emb[f]] = sub[o:o + q_emb[f]]
+            o += q_emb[f]
+        res = assign_batch(aug_f, q_emb[frames], num_per_length, self.assign_threads)
+        for i, f in enumerate(frames):
+            assns[f] = res[i]
+
+    def _assign_full(self, aug_h, row0, q_emb, num_per_length, tick):
+        F = len(q_emb)
+        aug_f = np.ones((F, 7, aug_h.shape[1]), dtype=np.float16)
+        for f in range(F):
+            aug_f[f, :q_emb[f]] = aug_h[row0[f]:row0[f] + q_emb[f]]
+        assns = assign_batch(aug_f, q_emb, num_per_length, self.assign_threads)
+        tick("assign")
+        return assns
+
+    # ---- schedulers --------------------------------------------------------------------------------------------------------
     def localise_concurrent(self, batches, workers=2, worker_arena_bytes=8 << 30, **kw):
         """`localise_batch` for a sequence of frame batches (dicts like `localise_stream` takes) on `workers` concurrent lanes: every
         lane is a host thread with its own HIP stream, registration scratch arena and encoder workspace, and runs whole batches
@@ -119,12 +228,14 @@ class LocaliseEngine:
         `localise_batch`, yielded in order."""
         import queue
         from collections import deque
+        if self.exchange is not None:
+            raise ValueError("localise_concurrent with a sharded memory: collectives must be issued by one thread (use localise_stream)")
         dev = self.memory.mem_emb.device
-        if self.reuse_features:                              # build the resident memory features before the lanes start
+        if self.reuse_features and self.memory.clouds is not None:     # build the resident memory features before the lanes start
             self.memory.features(kw.get("fpfh_voxel_size", 0.05), kw.get("fpfh_local_dist_factor", 0.4))
         while len(self._lanes) < workers:
             k = len(self._lanes)
-            self._lanes.append(_Lane(RegContext(worker_arena_bytes), ThreadPoolExecutor(max_workers=1), k, torch.cuda.Stream(device=dev)))
+            self._lanes.append(_Lane(RegContext(worker_arena_bytes), k, torch.cuda.Stream(device=dev)))
         free = queue.Queue()
         cur = torch.cuda.current_stream(dev)
         for lane in self._lanes[:workers]:
@@ -158,18 +269,20 @@ class LocaliseEngine:
 
     def localise_stream(self, batches, **kw):
         """Pipelined form of `localise_batch` for a sequence of frame batches (dicts with det, q_per_frame and crops or det_emb,
-        optionally seed / job_id_base): embed + match of batch k + 1 run on a second stream, driven by a worker thread, while batch
-        k is assigned (host) and registered; results are those of `localise_batch`, yielded in order.  The two stages touch
-        disjoint state: the encoder / match workspaces belong to stage A, the registration arena to stage B."""
+        optionally seed / job_id_base): stage A (embed, match, candidates, assignment search, every collective) of batch k + 1
+        runs on a second stream, driven by a worker thread, while stage B of batch k (registration) executes; results are those
+        of `localise_batch`, yielded in order.  The two stages touch disjoint state: the encoder / match workspaces belong to
+        stage A, the registration arena to stage B."""
         dev = self.memory.mem_emb.device
         side = torch.cuda.Stream(device=dev)      # equal priority: raising either stage's stream priority measured 7-8 % slower
         main = torch.cuda.current_stream(dev)
+        npl = kw.get("num_per_length", 4)
 
         def stage_a(b, ready):
             torch.cuda.set_device(dev)                      # worker thread: current device and stream are per thread
             with torch.cuda.stream(side):
                 side.wait_event(ready)                      # this batch's inputs (crops) were produced on the caller's stream
-                return self._embed_match(b.get("crops"), b.get("det_emb"))
+                return self.match_assign(b["q_per_frame"], b.get("crops"), b.get("det_emb"), npl)
 
         def submit(b):
             # `batches` may be a lazy iterator whose crops are written by kernels on the caller's stream as it is advanced: the
@@ -187,7 +300,7 @@ class LocaliseEngine:
         fut = submit(cur)
         try:
             while cur is not None:
-                aug_h = fut.result()
+                assns = fut.result()
                 fut = None
                 nxt = next(it, None)
                 if nxt is not None:
@@ -196,7 +309,7 @@ class LocaliseEngine:
                 for k in ("seed", "job_id_base"):
                     if k in cur:
                         args[k] = cur[k]
-                yield self.localise_batch(cur["det"], cur["q_per_frame"], aug_h=aug_h, **args)
+                yield self.localise_batch(cur["det"], cur["q_per_frame"], assns=assns, **args)
                 cur = nxt
         finally:
             # an abandoned generator or a raising batch must not leave stage A running on the side stream with the lane-0 encoder
@@ -208,16 +321,17 @@ class LocaliseEngine:
                     pass
             side.synchronize()
 
+    # ---- one batch -----------------------------------------------------------------------------------------------------------
     def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
                        fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, outlier_radius=0.05, outlier_nb_points=8,
                        seed=0, job_id_base=0, ransac_max_iter=4000000, num_per_length=4, eval_threshold=None, timings=None,
-                       aug_h=None, _slot=None, register=True):
+                       assns=None, _slot=None, register=True):
         """det: detected clouds of all frames (segments in frame order, <= 7 per frame); crops: uint8 tensor
-        (sum Q, H, W, 3) or list of arrays, or det_emb: (sum Q, D) precomputed embeddings (or aug_h: the host similarity rows
-        stage A of `localise_stream` produced).  register=False stops after the assignment search (embedding-only memories):
-        the results carry the assignment lists, `best` = 0 and identity poses; `det` may then be None."""
+        (sum Q, H, W, 3) or list of arrays (DATOR: the (rgb, depth) pair), or det_emb: (sum Q, D) precomputed embeddings (or
+        assns: the assignment lists stage A of `localise_stream` produced).  register=False stops after the assignment search
+        (embedding-only memories): the results carry the assignment lists, `best` = 0 and identity poses; `det` may be None."""
         mem = self.memory
-        ctx, pool, lane = (self.ctx, self._pool, 0) if _slot is None else (_slot.ctx, _slot.pool, _slot.lane)
+        ctx, lane = (self.ctx, 0) if _slot is None else (_slot.ctx, _slot.lane)
         q_per_frame = np.asarray(q_per_frame, dtype=np.int32)
         F = len(q_per_frame)
         row0 = np.concatenate([[0], np.cumsum(q_per_frame)]).astype(np.int64)
@@ -231,43 +345,33 @@ class LocaliseEngine:
                 e.record()
                 ev.append((name, e))
 
+        def close_timings():
+            if timings is not None:
+                torch.cuda.synchronize()
+                for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+                    timings[n1] = timings.get(n1, 0.0) + e0.elapsed_time(e1)
+
         tick("start")
-        # ---- embed + match (GPU) -------------------------------------------------------------------
-        aug = self._embed_match(crops, det_emb, tick, to_host=False, lane=lane) if aug_h is None else None
+        # ---- stage A: embed + match + assign (:911-982) -----------------------------------------------
+        if assns is None:
+            assns = self.match_assign(q_per_frame, crops, det_emb, num_per_length, lane, tick)
+        results = [FrameResult(np.array([0., 0., 0., 0., 0., 0., 1.]), np.array([0., 0., 0., 0., 0., 0., 1.])) for _ in range(F)]
+        if not register:
+            for f in range(F):
+                results[f].assignments = assns[f]
+                results[f].best = 0 if assns[f] else -1
+            close_timings()
+            return results
         # ---- clean the detected clouds (:992-998) ---------------------------------------------------
-        if register:
-            keep = radius_outlier_batch(ctx, det, outlier_radius, outlier_nb_points)
-            keepb = keep.bool()
-            csum = torch.cumsum(keep.to(torch.int32), 0)
-            csum0 = torch.cat([torch.zeros(1, dtype=torch.int32, device=csum.device), csum])
-            new_off = csum0[det.seg_off.long()]
-            clean_pts = det.pts4[keepb].contiguous()
+        keep = radius_outlier_batch(ctx, det, outlier_radius, outlier_nb_points)
+        keepb = keep.bool()
+        csum = torch.cumsum(keep.to(torch.int32), 0)
+        csum0 = torch.cat([torch.zeros(1, dtype=torch.int32, device=csum.device), csum])
+        new_off = csum0[det.seg_off.long()]
+        clean_pts = det.pts4[keepb].contiguous()
+        new_off_h = new_off.cpu().numpy().astype(np.int32)
+        clean = CloudBatch(clean_pts, new_off_h)
         tick("outlier")
-        # ---- one host round trip: fp16 similarity rows + cleaned sizes ------------------------------
-        if aug_h is None:
-            aug_h = aug.cpu().numpy()
-        if register:
-            new_off_h = new_off.cpu().numpy().astype(np.int32)
-            clean = CloudBatch(clean_pts, new_off_h)
-        tick("d2h")
-        # ---- assign (host, exact similarity-volume search; :974-982) --------------------------------
-        M = mem.M
-        aug_f = np.ones((F, 7, M + 1), dtype=np.float16)
-        q_emb = np.minimum(q_per_frame, M)
-        for f in range(F):
-            if q_per_frame[f] > 7:
-                raise ValueError("more than 7 detections in a frame: select the 7 largest first (object_memory.py:900-908)")
-            if q_emb[f] < min(q_per_frame[f], 3):
-                raise AssertionError("fewer memory objects than the sub-volume dimension (reference asserts at similarity_volume.py:112)")
-            aug_f[f, :q_emb[f]] = aug_h[row0[f]:row0[f] + q_emb[f]]
-        # The detections' instance features (normals / FPFH, once per frame batch instead of once per assignment) only need the
-        # cleaned clouds, so the GPU computes them while the host cores run the assignment search (both calls release the GIL).
-        det_feat_job = None
-        if self.reuse_features and register:
-            det_feat_job = pool.submit(self._det_features, clean, fpfh_voxel_size, ctx, torch.cuda.current_stream())
-        assns = assign_batch(aug_f, q_emb, num_per_length, self.assign_threads)
-        det_feat = det_feat_job.result() if det_feat_job is not None else None
-        tick("assign")
         # ---- registration jobs (:1020-1106) ----------------------------------------------------------
         job_frame, job_src, job_tgt = [], [], []
         for f in range(F):
@@ -275,20 +379,16 @@ class LocaliseEngine:
                 job_frame.append(f)
                 job_src.append([int(row0[f]) + d for d, m in a] + [-1] * (3 - len(a)))
                 job_tgt.append([m for d, m in a] + [-1] * (3 - len(a)))
-        results = [FrameResult(np.array([0., 0., 0., 0., 0., 0., 1.]), np.array([0., 0., 0., 0., 0., 0., 1.])) for _ in range(F)]
-        if not register:
-            for f in range(F):
-                results[f].assignments = assns[f]
-                results[f].best = 0 if assns[f] else -1
-        if not job_frame or not register:
-            if timings is not None:
-                torch.cuda.synchronize()
-                for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
-                    timings[n1] = timings.get(n1, 0.0) + e0.elapsed_time(e1)
+        if not job_frame:
+            close_timings()
             return results
-        J = len(job_frame)
-        # instance features: the memory's are resident (built on first use), the detections' were computed above
-        mem_feat = mem.features(fpfh_voxel_size, fpfh_local_dist_factor) if self.reuse_features else None
+        # instance features (normals / FPFH, once per cloud instead of once per assignment): the memory's are resident (built on
+        # first use), the detections' are computed here once per frame batch
+        det_feat = mem_feat = None
+        if self.reuse_features:
+            det_feat = instance_features_batch(ctx, clean, fpfh_voxel_size)
+            mem_feat = mem.features(fpfh_voxel_size, fpfh_local_dist_factor)
+        tick("det_features")
         reg = register_batch(ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
                              fpfh_local_dist_factor, seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter,
                              have_colors=True, center=True, det_features=det_feat, mem_features=mem_feat)
@@ -334,8 +434,5 @@ class LocaliseEngine:
             results[f] = FrameResult(np.concatenate((t_ref, q)), np.concatenate((t_fix, q)), assns[f], recs, best,
                                      int(new_off_h[row0[f + 1]] - new_off_h[row0[f]]))
         tick("select")
-        if timings is not None:
-            torch.cuda.synchronize()
-            for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
-                timings[n1] = timings.get(n1, 0.0) + e0.elapsed_time(e1)
+        close_timings()
         return results

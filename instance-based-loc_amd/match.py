@@ -38,3 +38,30 @@ def closest_similarity(det: torch.Tensor, mem: torch.Tensor, emb_offsets: torch.
                                          aug.data_ptr() if want_aug else None, ws.data_ptr(), ws_bytes, _stream())
     _lib.check(st, "ibl_closest_similarity")
     return sims, aug
+
+
+def match_topk(det: torch.Tensor, mem: torch.Tensor, emb_offsets: torch.Tensor, k_hi: int, k_lo: int, index_base: int = 0,
+               want_aug: bool = True):
+    """Closest similarity of every query row against this rank's memory rows, then the per-row two-ended candidates
+    (`ibl_match_topk`): the k_hi largest and k_lo smallest fp16 `aug` entries under (value, lower index first), as
+    (cand_val (Nq, S) float16, cand_idx (Nq, S) int32 = index_base + local index, cand_cnt (Nq, 2) int32 [n_hi, n_lo]), S = k_hi + k_lo.
+    A row with at most S columns is returned whole (n_hi = columns, n_lo = 0).  With want_aug also the full (Nq, M + 1) fp16 rows
+    (they stay on the device; only frames whose candidate search cannot be proved exact are fetched)."""
+    for t in (det, mem):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()
+    assert emb_offsets.is_cuda and emb_offsets.dtype == torch.int32
+    nq, dim = det.shape
+    nrows = mem.shape[0]
+    n_inst = emb_offsets.numel() - 1
+    S = k_hi + k_lo
+    ws_bytes = _lib.lib.ibl_match_topk_workspace_bytes(nq, nrows, n_inst)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=det.device)
+    val = torch.zeros((nq, S), dtype=torch.float16, device=det.device)
+    idx = torch.full((nq, S), -1, dtype=torch.int32, device=det.device)
+    cnt = torch.zeros((nq, 2), dtype=torch.int32, device=det.device)
+    aug = torch.empty((nq, n_inst + 1), dtype=torch.float16, device=det.device) if want_aug else None
+    st = _lib.lib.ibl_match_topk(det.data_ptr(), nq, mem.data_ptr(), nrows, emb_offsets.data_ptr(), n_inst, dim, int(k_hi), int(k_lo),
+                                 int(index_base), val.data_ptr(), idx.data_ptr(), cnt.data_ptr(), aug.data_ptr() if want_aug else None,
+                                 ws.data_ptr(), ws_bytes, _stream())
+    _lib.check(st, "ibl_match_topk")
+    return val, idx, cnt, aug

@@ -1,7 +1,19 @@
-"""Multi-GPU layout of the path: query frames are data-parallel (no communication); the memory
-embeddings can additionally be sharded by instance range, in which case every rank computes its block of the
-closest-similarity matrix and the blocks are all-gathered (RCCL over xGMI; backend "nccl" on ROCm, "gloo" in the
-CPU tests) before the exact assignment search."""
+"""Multi-GPU layout of the path.  One process per GPU; `torch.distributed` is the transport (backend "nccl" IS RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+* Query frames are data-parallel: every rank localises its own frames -- no communication.
+* The embedding memory can be sharded by contiguous instance range (`shard_range`).  Per step every rank then
+    1. all-gathers the L2-normalised query embeddings of all ranks (R x D fp32 per rank; 688 KB for 224 rows of 768),
+    2. matches ALL ranks' rows against ITS instance range and keeps, per row, the k_hi largest / k_lo smallest fp16 similarities
+       with their GLOBAL instance indices (`ibl_match_topk`, csrc/topk.hip),
+    3. all-gathers those candidate lists ((6 S + 8) bytes per row and shard, S = k_hi + k_lo: 1.3 KB -- the north star's "RCCL
+       all-gather of per-shard top-k matches over xGMI before registration"),
+   and the owner of a frame merges the per-shard lists and runs the assignment search on them (`ibl_assign_candidates`), which proves
+   per frame that the result equals the search on the full rows.  A frame it cannot prove (ties at the candidate threshold) is redone
+   on full rows: the ranks agree with one all-reduce(MAX) of a flag and all-gather their similarity blocks for that step only.
+* Whole-memory evaluation with the clouds sharded: all-reduce(MIN) of per-point nearest distances (`evaluate_sharded`).
+All collectives of a step are issued by ONE thread in a fixed order (LocaliseEngine's stage A), so they pair up across ranks.
+"""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -18,9 +30,85 @@ def frames_for_rank(n_frames: int, rank: int, world: int):
     return range(*shard_range(n_frames, rank, world))
 
 
+def pack_candidates(val: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor) -> torch.Tensor:
+    """(R, S) fp16 values, (R, S) int32 global indices, (R, 2) int32 counts -> one (R, S + S/2 + 2) int32 payload."""
+    assert val.dtype == torch.float16 and idx.dtype == torch.int32 and cnt.dtype == torch.int32 and val.shape[1] % 2 == 0
+    return torch.cat([idx, val.contiguous().view(torch.int32), cnt], dim=1).contiguous()
+
+
+def unpack_candidates(buf: torch.Tensor, S: int):
+    idx = buf[..., :S]
+    val = buf[..., S:S + S // 2].contiguous().view(torch.float16)
+    cnt = buf[..., S + S // 2:]
+    return val, idx, cnt
+
+
+def merge_lists_host(val: np.ndarray, idx: np.ndarray, cnt: np.ndarray):
+    """Per-shard candidate lists of the same rows, (W, R, S) / (W, R, S) / (W, R, 2) host arrays -> (R, W * S) lists with the valid
+    entries first and (R,) counts: the layout `ibl_assign_candidates` takes (it selects the overall k_hi / k_lo itself)."""
+    W, R, S = val.shape
+    n = cnt.sum(axis=2)                                                  # (W, R) valid entries per shard
+    valid = np.arange(S)[None, None, :] < n[:, :, None]                  # (W, R, S)
+    v = np.transpose(val, (1, 0, 2)).reshape(R, W * S)
+    j = np.transpose(idx, (1, 0, 2)).reshape(R, W * S)
+    m = np.transpose(valid, (1, 0, 2)).reshape(R, W * S)
+    order = np.argsort(~m, axis=1, kind="stable")                        # valid entries first, source order kept
+    return np.take_along_axis(v, order, 1), np.take_along_axis(j, order, 1), n.sum(axis=0).astype(np.int32)
+
+
+class ShardExchange:
+    """The collectives of one rank's stage A when the embedding memory is sharded over `group`.  rows_cap: fixed number of query
+    rows every rank contributes per step (shorter batches are zero-padded), so that no size has to be negotiated."""
+
+    def __init__(self, group=None, rows_cap: int = 224):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.cap = int(rows_cap)
+
+    def gather_queries(self, detn: torch.Tensor) -> torch.Tensor:
+        """(R, D) normalised query rows of this rank -> (W * cap, D): rank r's rows at [r * cap, r * cap + R_r), zeros after."""
+        R, D = detn.shape
+        if R > self.cap:
+            raise ValueError(f"{R} query rows in a step, rows_cap is {self.cap}")
+        mine = torch.zeros((self.cap, D), dtype=detn.dtype, device=detn.device)
+        mine[:R] = detn
+        out = torch.empty((self.world * self.cap, D), dtype=detn.dtype, device=detn.device)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        return out
+
+    def gather_candidates(self, val: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor):
+        """This rank's lists for all W * cap rows -> the lists of every shard for THIS rank's rows: (W, cap, S) / (W, cap, S) / (W, cap, 2)."""
+        S = val.shape[1]
+        mine = pack_candidates(val, idx, cnt)                             # (W * cap, P)
+        out = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        own = out[:, self.rank * self.cap:(self.rank + 1) * self.cap]     # (W, cap, P)
+        return unpack_candidates(own, S)
+
+    def any_flag(self, flag: bool, device) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item())
+
+    def gather_blocks(self, aug_local: torch.Tensor, n_inst: int) -> torch.Tensor:
+        """aug_local (W * cap, M_s + 1) fp16 rows of this rank's instance range (last column = the constant 1) -> the full (cap, M + 1)
+        rows of this rank's queries.  Ranges differ by at most one instance: blocks are padded to the widest for the collective."""
+        widths = [shard_range(n_inst, r, self.world)[1] - shard_range(n_inst, r, self.world)[0] for r in range(self.world)]
+        wmax = max(widths)
+        mine = torch.zeros((aug_local.shape[0], wmax), dtype=aug_local.dtype, device=aug_local.device)
+        mine[:, :aug_local.shape[1] - 1] = aug_local[:, :-1]
+        out = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        own = out[:, self.rank * self.cap:(self.rank + 1) * self.cap]
+        full = torch.cat([own[r, :, :w] for r, w in enumerate(widths)] +
+                         [torch.ones((self.cap, 1), dtype=aug_local.dtype, device=aug_local.device)], dim=1)
+        return full
+
+
 def allgather_similarity_blocks(local_block: torch.Tensor, n_inst: int, group=None) -> torch.Tensor:
-    """local_block: (Nq, hi - lo) similarities of this rank's instance range -> (Nq, n_inst) on every rank.
-    Shards may differ by one column, so blocks are padded to the widest shard for the collective."""
+    """local_block: (Nq, hi - lo) similarities of this rank's instance range for the SAME query rows on every rank -> (Nq, n_inst) on
+    every rank.  Shards may differ by one column, so blocks are padded to the widest shard for the collective."""
     world = dist.get_world_size(group)
     widths = [shard_range(n_inst, r, world)[1] - shard_range(n_inst, r, world)[0] for r in range(world)]
     wmax = max(widths)
@@ -38,7 +126,6 @@ def augment_half(sims: torch.Tensor) -> np.ndarray:
     aug = np.ones((s.shape[0], s.shape[1] + 1), dtype=np.float16)
     aug[:, :-1] = s
     return aug
-
 
 
 def fitness_rmse_from_d2(d2: torch.Tensor, job_sizes):
