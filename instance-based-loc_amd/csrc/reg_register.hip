@@ -11,6 +11,8 @@
 // sequential scan that reproduces the "better result / confidence-based early exit" bookkeeping exactly.
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
+
+#include <memory>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -1560,7 +1562,8 @@ __global__ __launch_bounds__(256) void ibl_mg_insert_kernel(const unsigned long 
 extern "C" int ibl_memgrid_build(ibl_reg_ctx* ctx, const float* mem_pts4, int64_t n, double cell, ibl_memgrid** out, void* stream) {
     if (!ctx || !mem_pts4 || !out || n <= 0 || n > 0x7FFFFFF0ll || cell <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_memgrid_build: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    ibl_memgrid* g = new ibl_memgrid();
+    std::unique_ptr<ibl_memgrid> owner(new ibl_memgrid());      // freed on every error return below
+    ibl_memgrid* g = owner.get();
     g->cell = (float)cell; g->inv = 1.0f / (float)cell; g->n = n;
     const float4* P = reinterpret_cast<const float4*>(mem_pts4);
     // persistent part (stays allocated in the arena until the context is destroyed)
@@ -1607,7 +1610,7 @@ extern "C" int ibl_memgrid_build(ibl_reg_ctx* ctx, const float* mem_pts4, int64_
         IBL_LAUNCH_CHECK();
         IBL_HIP_CHECK(hipStreamSynchronize(s));
     }
-    *out = g;
+    *out = owner.release();
     return IBL_OK;
 }
 

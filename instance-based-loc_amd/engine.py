@@ -27,7 +27,7 @@ from scipy.spatial.transform import Rotation
 
 from . import match
 from .assign import K_HI, K_LO, assign_batch, assign_candidates
-from .parallel import ShardExchange, merge_lists_host, shard_range
+from .parallel import ShardExchange, shard_range, sharded_candidates
 from .registration import (CloudBatch, MemGrid, RegContext, evaluate_batch, instance_features_batch, radius_outlier_batch,
                            register_batch)
 
@@ -175,11 +175,9 @@ class LocaliseEngine:
             val_h, idx_h = val.cpu().numpy(), idx.cpu().numpy()
             cnt_h = cnt.cpu().numpy().sum(axis=1).astype(np.int32)
         else:
-            allq = ex.gather_queries(detn)                                          # (W * cap, D)
-            val, idx, cnt, aug = match.match_topk(allq, mem.mem_emb, mem.emb_offsets, self.k_hi, self.k_lo, mem.lo)
+            val_h, idx_h, cnt_h, aug = sharded_candidates(
+                ex, detn, lambda rows: match.match_topk(rows, mem.mem_emb, mem.emb_offsets, self.k_hi, self.k_lo, mem.lo))
             tick("match")
-            gv, gi, gc = ex.gather_candidates(val, idx, cnt)                        # (W, cap, S) lists of this rank's rows
-            val_h, idx_h, cnt_h = merge_lists_host(gv[:, :R].cpu().numpy(), gi[:, :R].cpu().numpy(), gc[:, :R].cpu().numpy())
         tick("d2h")
         assns, exact = assign_candidates(val_h, idx_h, cnt_h, row0[:-1], q_emb, mem.M, self.k_hi, self.k_lo, num_per_length,
                                          self.assign_threads)

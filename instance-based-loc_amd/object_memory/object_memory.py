@@ -78,6 +78,7 @@ class ObjectMemory():
         self.floors = None
         self._ctx = RegContext(arena_bytes)
         self._engine = None
+        self._shard = None
         self.ransac_seed = 0
         self._n_queries = 0
 
@@ -316,8 +317,10 @@ class ObjectMemory():
         if self._engine is None:
             if not self.memory:
                 raise RuntimeError("object memory is empty")
+            if self._shard is not None:          # a rebuilt memory: release the previous spatial hash's host record, then its arena
+                self._shard.close()
             self._ctx.reset()
-            shard = MemoryShard(self._ctx, [np.stack(m.embeddings).astype(np.float32) for m in self.memory],
+            shard = self._shard = MemoryShard(self._ctx, [np.stack(m.embeddings).astype(np.float32) for m in self.memory],
                                 [np.asarray(m.pointcloud.points) for m in self.memory],
                                 colors=[np.asarray(m.pointcloud.colors) for m in self.memory], device=self.device)
             self._engine = LocaliseEngine(shard)

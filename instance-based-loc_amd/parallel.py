@@ -81,9 +81,9 @@ class ShardExchange:
         """This rank's lists for all W * cap rows -> the lists of every shard for THIS rank's rows: (W, cap, S) / (W, cap, S) / (W, cap, 2)."""
         S = val.shape[1]
         mine = pack_candidates(val, idx, cnt)                             # (W * cap, P)
-        out = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(out, mine, group=self.group)
-        own = out[:, self.rank * self.cap:(self.rank + 1) * self.cap]     # (W, cap, P)
+        out = torch.empty((self.world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=self.group)          # (concatenated form: the one gloo implements too)
+        own = out.view(self.world, mine.shape[0], mine.shape[1])[:, self.rank * self.cap:(self.rank + 1) * self.cap]     # (W, cap, P)
         return unpack_candidates(own, S)
 
     def any_flag(self, flag: bool, device) -> bool:
@@ -98,12 +98,25 @@ class ShardExchange:
         wmax = max(widths)
         mine = torch.zeros((aug_local.shape[0], wmax), dtype=aug_local.dtype, device=aug_local.device)
         mine[:, :aug_local.shape[1] - 1] = aug_local[:, :-1]
-        out = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        out = torch.empty((self.world * mine.shape[0], wmax), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(out, mine, group=self.group)
-        own = out[:, self.rank * self.cap:(self.rank + 1) * self.cap]
+        own = out.view(self.world, mine.shape[0], wmax)[:, self.rank * self.cap:(self.rank + 1) * self.cap]
         full = torch.cat([own[r, :, :w] for r, w in enumerate(widths)] +
                          [torch.ones((self.cap, 1), dtype=aug_local.dtype, device=aug_local.device)], dim=1)
         return full
+
+
+def sharded_candidates(ex: ShardExchange, detn: torch.Tensor, match_fn):
+    """Steps 1-3 of the sharded match for one batch of this rank's R normalised query rows.  match_fn(all_rows (W * cap, D)) ->
+    (val, idx, cnt, aug_local) is the rank-local match of ALL ranks' rows against this rank's instance range with GLOBAL indices
+    (`match.match_topk(..., index_base=lo)` on the GPU).  Returns the merged host lists of this rank's rows -- (R, W * S) values,
+    (R, W * S) indices, (R,) counts, ready for `assign.assign_candidates` -- and aug_local for the full-row fall-back."""
+    R = detn.shape[0]
+    allq = ex.gather_queries(detn)
+    val, idx, cnt, aug_local = match_fn(allq)
+    gv, gi, gc = ex.gather_candidates(val, idx, cnt)
+    val_h, idx_h, cnt_h = merge_lists_host(gv[:, :R].cpu().numpy(), gi[:, :R].cpu().numpy(), gc[:, :R].cpu().numpy())
+    return val_h, idx_h, cnt_h, aug_local
 
 
 def allgather_similarity_blocks(local_block: torch.Tensor, n_inst: int, group=None) -> torch.Tensor:

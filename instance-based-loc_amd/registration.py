@@ -240,6 +240,12 @@ class MemGrid:
             _lib.lib.ibl_memgrid_destroy(self._h)
             self._h = C.c_void_p()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     @property
     def handle(self):
         return self._h

@@ -136,3 +136,88 @@ def test_sharded_evaluate_allreduce_min_gloo_world2(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                           "127.0.0.1", "--master-port", "29519", str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "EVAL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+TOPK_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["IBL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from ibloc_amd.assign import assign_batch, assign_candidates
+from ibloc_amd.parallel import ShardExchange, shard_range, sharded_candidates
+from tests.test_assign_candidates import select_np
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+K_HI, K_LO, CAP = 192, 32, 24
+QUANT = 0
+rng = np.random.default_rng(77)                      # same memory on every rank
+M, E, D = 1501, 2, 48
+base = rng.normal(size=(M, D))
+mem = base[:, None, :] + rng.normal(0, 0.3, size=(M, E, D))
+mem /= np.linalg.norm(mem, axis=-1, keepdims=True)
+lo, hi = shard_range(M, rank, world)
+
+def full_rows(q):                                    # [closest similarity | 1] in fp16 against a range of instances
+    def rows(a, b):
+        s = np.einsum("qd,med->qme", q.astype(np.float32), mem[a:b].astype(np.float32)).max(-1)
+        if QUANT:
+            s = np.where(s > 0.6, 0.75, 0.5)             # two similarity levels only: every row ties massively at the threshold
+        out = np.ones((len(q), b - a + 1), dtype=np.float16)
+        out[:, :-1] = s
+        return out
+    return rows
+
+def match_local(allq):                               # what ibl_match_topk does on the GPU, restated with numpy
+    aug = full_rows(allq.numpy())(lo, hi)
+    R, S = len(aug), K_HI + K_LO
+    val, idx, cnt = np.zeros((R, S), np.float16), np.full((R, S), -1, np.int32), np.zeros((R, 2), np.int32)
+    for r in range(R):
+        v, j = select_np(aug[r, :-1], lo, K_HI, K_LO)
+        val[r, :len(v)], idx[r, :len(v)] = v, j
+        cnt[r] = (K_HI, K_LO) if hi - lo > S else (hi - lo, 0)
+    return torch.from_numpy(val), torch.from_numpy(idx), torch.from_numpy(cnt), torch.from_numpy(aug)
+
+ex = ShardExchange(None, CAP)
+frng = np.random.default_rng(100 + rank)             # every rank has its own frames
+for step, kind in enumerate(["reid", "ties"]):
+    q_per_frame = np.array([7, 3, 1, 5] if rank == 0 else [2, 7, 7], dtype=np.int32)
+    ids = frng.integers(0, M, size=int(q_per_frame.sum()))
+    q = base[ids] + frng.normal(0, 0.25, size=(len(ids), D))
+    QUANT = 2 if kind == "ties" else 0
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    detn = torch.from_numpy(q.astype(np.float32))
+    val_h, idx_h, cnt_h, aug_local = sharded_candidates(ex, detn, match_local)
+    row0 = np.concatenate([[0], np.cumsum(q_per_frame)]).astype(np.int32)
+    got, exact = assign_candidates(val_h, idx_h, cnt_h, row0[:-1], q_per_frame, M, K_HI, K_LO, 4)
+    redo = np.nonzero(~exact)[0]
+    if ex.any_flag(len(redo) > 0, "cpu"):
+        full = ex.gather_blocks(aug_local, M)[:len(q)].numpy()
+        assert np.array_equal(full, full_rows(q)(0, M))        # the gathered blocks ARE the full rows
+        for f in redo:
+            a = np.ones((1, 7, M + 1), dtype=np.float16)
+            a[0, :q_per_frame[f]] = full[row0[f]:row0[f + 1]]
+            got[f] = assign_batch(a, [q_per_frame[f]], 4)[0]
+    want_aug = full_rows(q)(0, M)
+    for f in range(len(q_per_frame)):
+        a = np.ones((1, 7, M + 1), dtype=np.float16)
+        a[0, :q_per_frame[f]] = want_aug[row0[f]:row0[f + 1]]
+        assert got[f] == assign_batch(a, [q_per_frame[f]], 4)[0], (rank, kind, f)
+    if kind == "reid":
+        assert exact.all(), "re-identification rows must be proved from the candidate lists"
+    else:
+        assert not exact.all()                           # the fall-back (flag all-reduce + block all-gather) ran on this rank
+dist.barrier()
+if rank == 0:
+    print("TOPK_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_topk_allgather_gloo_world2(tmp_path):
+    """SURVEY §8e / north star: memory embeddings sharded by instance range, per-shard two-ended top-k candidate lists all-gathered,
+    exact assignment search on the merged lists (with the full-row fall-back agreed by all-reduce) == search on the full matrix"""
+    script = tmp_path / "topk_worker.py"
+    script.write_text(TOPK_WORKER)
+    env = dict(os.environ, IBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29521", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "TOPK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
