@@ -11,6 +11,16 @@
 #include "ibloc.h"
 #include "reg_common.h"
 
+// Cells per search radius of the hybrid k-NN grids: the max_nn nearest neighbours of a dense cloud sit in a small fraction of the
+// radius, and hybrid_select (reg_knn.hip) only walks the cube of cells that provably holds them.  (Per-segment cell sizes never drop
+// below extent / 128, reg_grid.hip.)
+#ifndef KNN_CELLS_NORMAL
+#define KNN_CELLS_NORMAL 3.0        // r = 2 voxel, 30 neighbours
+#endif
+#ifndef KNN_CELLS_FEATURE
+#define KNN_CELLS_FEATURE 5.0       // r = 5 voxel, 100 neighbours
+#endif
+
 int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
                        int* status, hipStream_t s);
 int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
@@ -100,7 +110,7 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
     {
         ArenaMark m2(ctx);
         BatchGrid g;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)radius_normal, (int64_t)64 << 20, &g, s);
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(radius_normal / KNN_CELLS_NORMAL), (int64_t)64 << 20, &g, s);
         if (st) return st;
         st = ibl_launch_normals(g, P, seg_off_dev, n, radius_normal, max_nn_normal, reinterpret_cast<float4*>(normals4), ctx->d_status, s);
         if (st) return st;
@@ -108,7 +118,7 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
     if (fpfh) {
         if (radius_feature <= 0 || max_nn_feature <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_normals_fpfh_batch: bad feature parameters");
         BatchGrid g;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)radius_feature, (int64_t)64 << 20, &g, s);
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(radius_feature / KNN_CELLS_FEATURE), (int64_t)64 << 20, &g, s);
         if (st) return st;
         unsigned char* spfh; int* nbr_idx; float* nbr_d2; int* nbr_cnt;
         IBL_ARENA(spfh, unsigned char, (int64_t)n * 36 + 64);
@@ -155,7 +165,7 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
     {
         ArenaMark mA(ctx);
         BatchGrid gA;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 2), (int64_t)128 << 20, &gA, s);
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 2 / KNN_CELLS_NORMAL), (int64_t)128 << 20, &gA, s);
         if (st) return st;
         st = ibl_launch_normals(gA, P, seg_off_dev, n, voxel_size * 2, 30, normals, ctx->d_status, s);
         if (st) return st;
@@ -163,7 +173,7 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
     if (fpfh) {
         ArenaMark mB(ctx);
         BatchGrid gB;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 5), (int64_t)64 << 20, &gB, s);
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 5 / KNN_CELLS_FEATURE), (int64_t)128 << 20, &gB, s);
         if (st) return st;
         unsigned char* spfh; float* nbr_d2; int *nbr_idx, *nbr_cnt;
         IBL_ARENA(spfh, unsigned char, (int64_t)n * 36 + 64);
@@ -181,7 +191,7 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
         if (grad_radius <= 0) return ibl_set_error(IBL_ERR_ARG, "colour gradients need a positive radius");
         ArenaMark mG(ctx);
         BatchGrid gG;      // cell = half the radius (the ICP correspondence distance), reach 2
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(grad_radius * 0.5), (int64_t)128 << 20, &gG, s);
+        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(grad_radius / KNN_CELLS_NORMAL), (int64_t)128 << 20, &gG, s);
         if (st) return st;
         st = ibl_launch_color_grad(gG, P, normals, seg_off_dev, gq0, gq1, grad_radius, 30, grad, ctx->d_status, s);
         if (st) return st;

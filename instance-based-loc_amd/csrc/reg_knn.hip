@@ -44,36 +44,73 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
                               WaveLds* L, Consumer& cons, int* status) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int reach = (int)ceilf(radius * sg.inv);
-    if (reach < 1) reach = 1;
+    int reach_max = (int)ceilf(radius * sg.inv);
+    if (reach_max < 1) reach_max = 1;
     const int cx = cell_clamp(q.x, sg.minx, sg.inv, sg.nx), cy = cell_clamp(q.y, sg.miny, sg.inv, sg.ny),
               cz = cell_clamp(q.z, sg.minz, sg.inv, sg.nz);
-    const int x0 = max(cx - reach, 0), x1 = min(cx + reach, sg.nx - 1);
-    const int y0 = max(cy - reach, 0), y1 = min(cy + reach, sg.ny - 1);
-    const int z0 = max(cz - reach, 0), z1 = min(cz + reach, sg.nz - 1);
     const float bscale = (float)KNN_BINS / r2;
 
-    // Candidate rows (runs of the cell-sorted point array, one per (z, y) of the neighbourhood).  A wave's walk is a chain of
-    // dependent latencies (row bounds -> points -> next row), and these kernels are bound by it, so the bounds of all rows
-    // are fetched in one step (lane r holds row r) and the first 64 points of three rows at a time are in flight together.
-    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-    int my_b = 0, my_e = 0;
-    if (nrows <= 64 && lane < nrows) {
-        const int z = z0 + lane / ny, y = y0 + lane % ny;
-        const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
-        my_b = g.cell_start[row + x0];
-        my_e = g.cell_start[row + x1 + 1];
+    // The grids are finer than the search radius (cell = radius / 3 .. radius / 5, reg_api.hip): with max_nn = 100 neighbours inside
+    // r = 0.25 m a dense cloud (5 000 points on a 0.5 m object) has ALL its points in radius, and scanning them twice per query
+    // was 90 % of the feature time.  The max_nn nearest are searched in the cube of `reach` cells around the query's cell first:
+    // that cube holds every point closer than reach * cell, so once max_nn candidates lie inside that ball the cube's k nearest
+    // are the cloud's k nearest (anything outside the cube is farther than all of them), and the result is the one of the full
+    // radius, bit for bit.  reach starts at the first cube whose population (read from the cell table, no distances) promises
+    // enough candidates and doubles when the ball count falls short.
+    int reach = reach_max;
+    for (int rho = 1; rho < reach_max; ++rho) {
+        const int xa = max(cx - rho, 0), xb = min(cx + rho, sg.nx - 1);
+        const int ya = max(cy - rho, 0), yb = min(cy + rho, sg.ny - 1);
+        const int za = max(cz - rho, 0), zb = min(cz + rho, sg.nz - 1);
+        const int nyr = yb - ya + 1, nr = nyr * (zb - za + 1);
+        int pop = 0;
+        for (int r = lane; r < nr; r += 64) {
+            const int row = sg.cell_base + ((za + r / nyr) * sg.ny + ya + r % nyr) * sg.nx;
+            pop += g.cell_start[row + xb + 1] - g.cell_start[row + xa];
+        }
+        pop = wave_sum_i(pop);
+        // a ball of radius rho * cell covers ~1/3 (rho = 1) .. ~1/2 of the surface patch its cube cuts out
+        if (pop >= (rho == 1 ? 3 : 2) * max_nn + 8) { reach = rho; break; }
     }
+    int x0, x1, y0, y1, z0, z1, ny, nrows, my_b, my_e;
+    auto set_reach = [&](int rho) {
+        x0 = max(cx - rho, 0); x1 = min(cx + rho, sg.nx - 1);
+        y0 = max(cy - rho, 0); y1 = min(cy + rho, sg.ny - 1);
+        z0 = max(cz - rho, 0); z1 = min(cz + rho, sg.nz - 1);
+        ny = y1 - y0 + 1; nrows = ny * (z1 - z0 + 1);
+        my_b = my_e = 0;
+        if (lane < nrows) {             // bounds of the first 64 candidate rows (runs of the cell-sorted point array, one per (z, y))
+            const int row = sg.cell_base + ((z0 + lane / ny) * sg.ny + y0 + lane % ny) * sg.nx;
+            my_b = g.cell_start[row + x0];
+            my_e = g.cell_start[row + x1 + 1];
+        }
+    };
+    // A wave's walk is a chain of dependent latencies (row bounds -> points -> next row), and these kernels are bound by it, so the
+    // bounds of 64 rows are fetched in one step (lane r holds row r), empty rows are dropped by ballot, and the first 64 points of
+    // three rows at a time are in flight together.
     auto scan = [&](auto&& f) {
-        if (nrows <= 64) {
-            for (int r0 = 0; r0 < nrows; r0 += 3) {
+        for (int rc = 0; rc < nrows; rc += 64) {
+            int cb = my_b, ce = my_e;
+            if (rc > 0) {
+                cb = ce = 0;
+                const int r = rc + lane;
+                if (r < nrows) {
+                    const int row = sg.cell_base + ((z0 + r / ny) * sg.ny + y0 + r % ny) * sg.nx;
+                    cb = g.cell_start[row + x0];
+                    ce = g.cell_start[row + x1 + 1];
+                }
+            }
+            unsigned long long live = __ballot(ce > cb);
+            while (live) {
                 int b[3], e[3];
                 float4 p[3];
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const int r = min(r0 + u, nrows - 1);
-                    b[u] = __shfl(my_b, r, 64);
-                    e[u] = r0 + u < nrows ? __shfl(my_e, r, 64) : b[u];
+                    const bool have = live != 0ull;
+                    const int r = have ? __ffsll((long long)live) - 1 : 0;
+                    if (have) live &= live - 1ull;
+                    b[u] = __shfl(cb, r, 64);
+                    e[u] = have ? __shfl(ce, r, 64) : b[u];
                     p[u] = b[u] + lane < e[u] ? g.sorted_pts[b[u] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
@@ -87,34 +124,30 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
                     }
                 }
             }
-            return;
         }
-        for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y) {
-                const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
-                const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-                for (int jb = b; jb < e; jb += 64) {
-                    const int j = jb + lane;
-                    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-                    float d2 = INFINITY;
-                    if (j < e) {
-                        p = g.sorted_pts[j];
-                        d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
-                    }
-                    f(d2 < r2, j, p, d2);
-                }
-            }
     };
     auto bin_of = [&](float d2) { int b = (int)(d2 * bscale); return b > KNN_BINS - 1 ? KNN_BINS - 1 : b; };
 
-    // ---- pass 1: histogram --------------------------------------------------------------------
+    // ---- pass 1: histogram (repeated on a larger cube while the ball inside the cube holds fewer than max_nn candidates) ------
+    for (;;) {
+        set_reach(reach);
 #pragma unroll
-    for (int t = 0; t < KNN_BINS / 64; ++t) L->hist[lane * (KNN_BINS / 64) + t] = 0;
-    wave_lds_sync();
-    scan([&](bool in, int, const float4&, float d2) {
-        if (in) atomicAdd(&L->hist[bin_of(d2)], 1);
-    });
-    wave_lds_sync();
+        for (int t = 0; t < KNN_BINS / 64; ++t) L->hist[lane * (KNN_BINS / 64) + t] = 0;
+        wave_lds_sync();
+        // every point closer than (reach - 0.001) cells is inside the cube (the margin covers the rounding of the cell index)
+        const float ball = ((float)reach - 1e-3f) / sg.inv;
+        const float ball2 = reach < reach_max ? ball * ball : INFINITY;
+        int in_ball = 0;
+        scan([&](bool in, int, const float4&, float d2) {
+            if (in) atomicAdd(&L->hist[bin_of(d2)], 1);
+            in_ball += (in && d2 < ball2) ? 1 : 0;
+        });
+        wave_lds_sync();
+        if (reach >= reach_max) break;
+        if (wave_sum_i(in_ball) >= max_nn) break;
+        reach = min(reach_max, 2 * reach);
+        wave_lds_sync();
+    }
     int hb[KNN_BINS / 64];
     int s = 0;
 #pragma unroll
@@ -133,16 +166,16 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
     if (!select_all) {
         const unsigned long long m = __ballot(incl >= max_nn);
         const int Lc = __ffsll((long long)m) - 1;
-        int my_b = 0, my_below = 0, my_pop = 0;
+        int bin_here = 0, my_below = 0, my_pop = 0;
         {
             int run = excl;
 #pragma unroll
             for (int t = 0; t < KNN_BINS / 64; ++t) {
-                if (my_pop == 0 && run + hb[t] >= max_nn) { my_b = lane * (KNN_BINS / 64) + t; my_below = run; my_pop = hb[t]; }
+                if (my_pop == 0 && run + hb[t] >= max_nn) { bin_here = lane * (KNN_BINS / 64) + t; my_below = run; my_pop = hb[t]; }
                 run += hb[t];
             }
         }
-        bstar = __shfl(my_b, Lc, 64);
+        bstar = __shfl(bin_here, Lc, 64);
         n_below = __shfl(my_below, Lc, 64);
         pop = __shfl(my_pop, Lc, 64);
     }
