@@ -21,16 +21,36 @@
 #define KNN_CELLS_FEATURE 5.0       // r = 5 voxel, 100 neighbours
 #endif
 
-int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
+#ifndef KNN_TILE_NORMAL
+#define KNN_TILE_NORMAL 4           // tile edge in cells of the 30-neighbour searches (normals, colour gradients)
+#endif
+#ifndef KNN_TILE_FEATURE
+#define KNN_TILE_FEATURE 2          // ... of the 100-neighbour SPFH search
+#endif
+
+int ibl_launch_normals(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
                        int* status, hipStream_t s);
-int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
+int ibl_launch_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
                     unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int matching_order, int* status,
                     hipStream_t s);
 int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,
                             unsigned char* keep, hipStream_t s);
 
-int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
+int ibl_launch_color_grad(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
                           int max_nn, float4* grad, int* status, hipStream_t s);
+
+// bounding boxes of the segments on the host (synchronises the stream)
+static int ibl_bbox_to_host(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, int n_seg, float* bbox_host, hipStream_t s) {
+    if (n_seg <= 0) return IBL_OK;
+    ArenaMark m(ctx);
+    float* bbox;
+    IBL_ARENA(bbox, float, (int64_t)n_seg * 6 + 6);
+    int st = ibl_launch_bbox(P, seg_off_dev, n_seg, bbox, s);
+    if (st) return st;
+    IBL_HIP_CHECK(hipMemcpyAsync(bbox_host, bbox, sizeof(float) * 6 * (size_t)n_seg, hipMemcpyDeviceToHost, s));
+    IBL_HIP_CHECK(hipStreamSynchronize(s));
+    return IBL_OK;
+}
 
 extern "C" int ibl_reg_ctx_create(ibl_reg_ctx** out, int64_t arena_bytes) {
     if (!out || arena_bytes < (1 << 20)) return ibl_set_error(IBL_ERR_ARG, "ibl_reg_ctx_create: bad argument");
@@ -47,6 +67,8 @@ extern "C" int ibl_reg_ctx_create(ibl_reg_ctx** out, int64_t arena_bytes) {
     c->used = 256;
     e = hipMemset(c->base, 0, 256);
     if (e != hipSuccess) { (void)hipFree(c->base); delete c; return ibl_set_error(IBL_ERR_HIP, "ibl_reg_ctx_create: memset failed"); }
+    c->pin_size = 32 << 20;            // pinned staging of the plan tables (job / pair / grid descriptors of one call)
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->pin), (size_t)c->pin_size, hipHostMallocDefault) != hipSuccess) { c->pin = nullptr; c->pin_size = 0; }
     *out = c;
     return IBL_OK;
 }
@@ -54,6 +76,7 @@ extern "C" int ibl_reg_ctx_create(ibl_reg_ctx** out, int64_t arena_bytes) {
 extern "C" int ibl_reg_ctx_destroy(ibl_reg_ctx* ctx) {
     if (!ctx) return IBL_OK;
     (void)hipFree(ctx->base);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     delete ctx;
     return IBL_OK;
 }
@@ -107,28 +130,35 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
     ArenaMark mark(ctx);
     hipStream_t s = (hipStream_t)stream;
     const float4* P = reinterpret_cast<const float4*>(pts4);
+    std::vector<float> bbox_host((size_t)n_seg * 6 + 6);
+    st = ibl_bbox_to_host(ctx, P, seg_off_dev, n_seg, bbox_host.data(), s);
+    if (st) return st;
     {
         ArenaMark m2(ctx);
         BatchGrid g;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(radius_normal / KNN_CELLS_NORMAL), (int64_t)64 << 20, &g, s);
+        st = ibl_build_tile_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, bbox_host.data(), radius_normal, max_nn_normal, KNN_TILE_NORMAL,
+                                 (int64_t)64 << 20, &g, s);
         if (st) return st;
-        st = ibl_launch_normals(g, P, seg_off_dev, n, radius_normal, max_nn_normal, reinterpret_cast<float4*>(normals4), ctx->d_status, s);
+        st = ibl_launch_normals(ctx, g, P, seg_off_dev, n, radius_normal, max_nn_normal, reinterpret_cast<float4*>(normals4), ctx->d_status, s);
         if (st) return st;
     }
     if (fpfh) {
         if (radius_feature <= 0 || max_nn_feature <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_normals_fpfh_batch: bad feature parameters");
         BatchGrid g;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(radius_feature / KNN_CELLS_FEATURE), (int64_t)64 << 20, &g, s);
+        st = ibl_build_tile_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, bbox_host.data(), radius_feature, max_nn_feature, KNN_TILE_FEATURE,
+                                 (int64_t)64 << 20, &g, s);
         if (st) return st;
         unsigned char* spfh; int* nbr_idx; float* nbr_d2; int* nbr_cnt;
         IBL_ARENA(spfh, unsigned char, (int64_t)n * 36 + 64);
         IBL_ARENA(nbr_idx, int, (int64_t)n * max_nn_feature + 64);
         IBL_ARENA(nbr_d2, float, (int64_t)n * max_nn_feature + 64);
         IBL_ARENA(nbr_cnt, int, n + 64);
-        st = ibl_launch_fpfh(g, P, reinterpret_cast<const float4*>(normals4), seg_off_dev, n, radius_feature, max_nn_feature, spfh,
+        st = ibl_launch_fpfh(ctx, g, P, reinterpret_cast<const float4*>(normals4), seg_off_dev, n, radius_feature, max_nn_feature, spfh,
                              nbr_idx, nbr_d2, nbr_cnt, fpfh, 0, ctx->d_status, s);
         if (st) return st;
     }
+    IBL_HIP_CHECK(hipStreamSynchronize(s));        // the pinned staging of the grid tables is recycled by the next call
+    ibl_stage_reset(ctx);
     return IBL_OK;
 }
 
@@ -156,31 +186,41 @@ __global__ __launch_bounds__(256) void ibl_fpfh_split_kernel(const float* __rest
     }
 }
 
-int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, double voxel_size,
-                          double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, unsigned short* fpfh_split, float* fpfh_norm,
-                          float4* grad, hipStream_t s) {
+// bbox_host: [n_seg][6] bounding boxes of the segments as ibl_launch_bbox computes them (the callers hold them: instance features
+// return them, a recomputed group's box is the union of its instances' boxes), or null: computed and read back here (one
+// synchronisation).  With the boxes on the host the three grids are dimensioned there: no further read-back.
+int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, const float* bbox_host,
+                          double voxel_size, double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, unsigned short* fpfh_split,
+                          float* fpfh_norm, float4* grad, hipStream_t s) {
     const int n = seg_off_host[n_seg];
     if (n <= 0) return IBL_OK;
     int st;
+    std::vector<float> own_bbox;
+    if (!bbox_host) {
+        own_bbox.resize((size_t)n_seg * 6 + 6);
+        st = ibl_bbox_to_host(ctx, P, seg_off_dev, n_seg, own_bbox.data(), s);
+        if (st) return st;
+        bbox_host = own_bbox.data();
+    }
     {
         ArenaMark mA(ctx);
         BatchGrid gA;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 2 / KNN_CELLS_NORMAL), (int64_t)128 << 20, &gA, s);
+        st = ibl_build_tile_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, bbox_host, voxel_size * 2, 30, KNN_TILE_NORMAL, (int64_t)128 << 20, &gA, s);
         if (st) return st;
-        st = ibl_launch_normals(gA, P, seg_off_dev, n, voxel_size * 2, 30, normals, ctx->d_status, s);
+        st = ibl_launch_normals(ctx, gA, P, seg_off_dev, n, voxel_size * 2, 30, normals, ctx->d_status, s);
         if (st) return st;
     }
     if (fpfh) {
         ArenaMark mB(ctx);
         BatchGrid gB;
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(voxel_size * 5 / KNN_CELLS_FEATURE), (int64_t)128 << 20, &gB, s);
+        st = ibl_build_tile_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, bbox_host, voxel_size * 5, 100, KNN_TILE_FEATURE, (int64_t)128 << 20, &gB, s);
         if (st) return st;
         unsigned char* spfh; float* nbr_d2; int *nbr_idx, *nbr_cnt;
         IBL_ARENA(spfh, unsigned char, (int64_t)n * 36 + 64);
         IBL_ARENA(nbr_idx, int, (int64_t)n * 100 + 64);
         IBL_ARENA(nbr_d2, float, (int64_t)n * 100 + 64);
         IBL_ARENA(nbr_cnt, int, n + 64);
-        st = ibl_launch_fpfh(gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
+        st = ibl_launch_fpfh(ctx, gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
         if (st) return st;
         if (fpfh_split && fpfh_norm) {
             hipLaunchKernelGGL(ibl_fpfh_split_kernel, dim3((unsigned)(((int64_t)n * 48 + 255) / 256)), dim3(256), 0, s, fpfh, n, fpfh_split, fpfh_norm);
@@ -190,10 +230,10 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
     if (grad && gq1 > gq0) {
         if (grad_radius <= 0) return ibl_set_error(IBL_ERR_ARG, "colour gradients need a positive radius");
         ArenaMark mG(ctx);
-        BatchGrid gG;      // cell = half the radius (the ICP correspondence distance), reach 2
-        st = ibl_build_batch_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, (float)(grad_radius / KNN_CELLS_NORMAL), (int64_t)128 << 20, &gG, s);
+        BatchGrid gG;
+        st = ibl_build_tile_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, bbox_host, grad_radius, 30, KNN_TILE_NORMAL, (int64_t)128 << 20, &gG, s);
         if (st) return st;
-        st = ibl_launch_color_grad(gG, P, normals, seg_off_dev, gq0, gq1, grad_radius, 30, grad, ctx->d_status, s);
+        st = ibl_launch_color_grad(ctx, gG, P, normals, seg_off_dev, gq0, gq1, grad_radius, 30, grad, ctx->d_status, s);
         if (st) return st;
     }
     return IBL_OK;
@@ -210,12 +250,11 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
     ArenaMark mark(ctx);
     hipStream_t s = (hipStream_t)stream;
     const float4* P = reinterpret_cast<const float4*>(pts4);
-    if (bbox_host && n_seg > 0) {
-        float* bbox;
-        IBL_ARENA(bbox, float, (int64_t)n_seg * 6 + 6);
-        st = ibl_launch_bbox(P, seg_off_dev, n_seg, bbox, s);
+    std::vector<float> own_bbox;
+    if (!bbox_host) { own_bbox.resize((size_t)n_seg * 6 + 6); bbox_host = own_bbox.data(); }
+    if (n_seg > 0) {
+        st = ibl_bbox_to_host(ctx, P, seg_off_dev, n_seg, bbox_host, s);        // the one synchronisation of this call before its end
         if (st) return st;
-        IBL_HIP_CHECK(hipMemcpyAsync(bbox_host, bbox, sizeof(float) * 6 * (size_t)n_seg, hipMemcpyDeviceToHost, s));
     }
     // chunks of whole clouds bound the scratch (800 B / point of neighbour lists): a 10k-instance memory is 50M points
     const int64_t chunk_pts = 1 << 20;
@@ -232,19 +271,24 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
             for (int i = 0; i <= ns; ++i) rebased[i] = seg_off_host[s0 + i] - o0;
             int* d;
             IBL_ARENA(d, int, ns + 1);
-            IBL_HIP_CHECK(hipMemcpyAsync(d, rebased.data(), sizeof(int) * (ns + 1), hipMemcpyHostToDevice, s));
-            IBL_HIP_CHECK(hipStreamSynchronize(s));     // `rebased` is rewritten by the next chunk
+            st = ibl_stage_upload(ctx, d, rebased.data(), sizeof(int) * (int64_t)(ns + 1), s);     // staged: `rebased` is rewritten by the next chunk
+            if (st) return st;
             off_dev = d;
             off_host = rebased.data();
         }
         const int cnt = off_host[ns];
-        st = ibl_features_on_batch(ctx, P + o0, off_dev, off_host, ns, voxel_size, grad_radius, 0, grad4 ? cnt : 0,
+        st = ibl_features_on_batch(ctx, P + o0, off_dev, off_host, ns, bbox_host + 6 * (size_t)s0, voxel_size, grad_radius, 0, grad4 ? cnt : 0,
                                    reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33, fpfh_split + (int64_t)o0 * 96,
                                    fpfh_norm + o0, grad4 ? reinterpret_cast<float4*>(grad4) + o0 : nullptr, s);
         if (st) return st;
         s0 = s1;
+        if (ctx->pin_used > ctx->pin_size / 2) {           // many chunks (a whole memory): recycle the staging buffer
+            IBL_HIP_CHECK(hipStreamSynchronize(s));
+            ibl_stage_reset(ctx);
+        }
     }
     IBL_HIP_CHECK(hipStreamSynchronize(s));
+    ibl_stage_reset(ctx);
     return IBL_OK;
 }
 

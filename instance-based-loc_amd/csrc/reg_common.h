@@ -22,6 +22,10 @@ struct BatchGrid {
     const float4* sorted_pts;  // [N] (x, y, z, intensity) in cell order
     const int* order;          // [N] sorted position -> original point index (batch-global)
     int n_seg;
+    // tiles (ibl_build_tile_grid only): cubes of ts^3 cells, one workgroup each in the LDS-staged k-NN kernels (reg_knn.hip)
+    const int* tile_base;      // [S + 1] first tile of every segment, or null
+    int n_tiles;
+    int ts;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -34,7 +38,18 @@ struct ibl_reg_ctx {
     int64_t high_water = 0;
     int device = 0;
     int* d_status = nullptr;      // device status word(s): bit flags set by kernels (overflow etc.)
+    // pinned host staging (bump allocator, reset by the entry point that used it after its final synchronisation): plan tables are
+    // copied here before their hipMemcpyAsync, so the copy is asynchronous (pageable sources make the runtime wait for the stream)
+    // and the caller's vectors may die at once
+    unsigned char* pin = nullptr;
+    int64_t pin_size = 0;
+    int64_t pin_used = 0;
 };
+
+// copies `bytes` of host data to the device through the context's pinned staging buffer, asynchronously on `s`; falls back to a
+// synchronous copy when the staging buffer is exhausted
+int ibl_stage_upload(ibl_reg_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes, hipStream_t s);
+static inline void ibl_stage_reset(ibl_reg_ctx* ctx) { ctx->pin_used = 0; }
 
 struct ArenaMark {
     ibl_reg_ctx* ctx;
@@ -77,6 +92,16 @@ static inline T* arena_alloc(ibl_reg_ctx* ctx, int64_t count, bool* ok) {
 // grid construction (reg_grid.hip)
 int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
                          float cell, int64_t max_cells, BatchGrid* out, hipStream_t s);
+// Grid for the hybrid k-NN kernels, sized on the HOST from the segments' bounding boxes (bbox_host [S][6], the values
+// ibl_launch_bbox produced): no read-back, no dims kernel.  The cell of a segment follows its point density (about max_nn points
+// inside a ball of two cells, clamped to [radius / 12, radius]), tiles are cubes of ts^3 cells.
+// Tile-grid tuning: the staging cube of a tile reaches ibl_knn_rho() cells past it, and the cell of a segment is sized so that the
+// ball of that many cells holds ibl_knn_safety() x max_nn points at the segment's mean surface density (clouds are uneven: edges,
+// corners and seams see half-empty balls).  Environment overrides IBL_KNN_RHO / IBL_KNN_SAFETY are for measurements.
+double ibl_knn_safety();
+int ibl_knn_rho();
+int ibl_build_tile_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
+                        const float* bbox_host, double radius, int max_nn, int ts, int64_t max_cells, BatchGrid* out, hipStream_t s);
 
 // per-segment axis-aligned bounding boxes [S][6] = (min xyz, max xyz); empty segments read as zeros
 int ibl_launch_bbox(const float4* pts, const int* seg_off_dev, int n_seg, float* bbox_dev, hipStream_t s);

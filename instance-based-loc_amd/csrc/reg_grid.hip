@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 #include "reg_common.h"
 
 // one block per segment: bounding box
@@ -144,25 +148,11 @@ __global__ __launch_bounds__(256) void ibl_gather_sorted_kernel(const float4* __
     if (i < n) sorted[i] = pts[order[i]];
 }
 
-int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
-                         float cell, int64_t max_cells, BatchGrid* out, hipStream_t s) {
-    const int n = seg_off_host[n_seg];
-    float* bbox; SegGrid* seg; int* total; int* cell_count; int* cell_start; unsigned *keys, *keys_out; int *vals, *order;
+// cell ids -> histogram -> exclusive scan -> stable radix sort -> gathered points, for a segment table already on the device
+static int grid_fill(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, int n_seg, int n, const SegGrid* seg, int h_total,
+                     BatchGrid* out, hipStream_t s) {
+    int* cell_count; int* cell_start; unsigned *keys, *keys_out; int *vals, *order;
     float4* sorted;
-    IBL_ARENA(bbox, float, (int64_t)n_seg * 6 + 6);
-    IBL_ARENA(seg, SegGrid, n_seg + 1);
-    IBL_ARENA(total, int, 4);
-    out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
-    if (n_seg == 0) return IBL_OK;
-    hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox);
-    IBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ibl_grid_dims_kernel, dim3(1), dim3(256), 0, s, bbox, n_seg, cell, (long long)max_cells, seg, total,
-                       ctx->d_status);
-    IBL_LAUNCH_CHECK();
-    int h_total = 0;
-    IBL_HIP_CHECK(hipMemcpyAsync(&h_total, total, sizeof(int), hipMemcpyDeviceToHost, s));
-    IBL_HIP_CHECK(hipStreamSynchronize(s));     // the table size decides the scan length (one small read-back per grid)
-    if (h_total <= 0 || h_total > max_cells) return ibl_set_error(IBL_ERR_OVERFLOW, "grid: %d cells exceed the budget %lld", h_total, (long long)max_cells);
     IBL_ARENA(cell_start, int, (int64_t)h_total + 2);
     IBL_ARENA(order, int, n + 1);
     IBL_ARENA(sorted, float4, n + 1);
@@ -192,4 +182,102 @@ int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off
     hipLaunchKernelGGL(ibl_gather_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, order, n, sorted);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
+}
+
+int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
+                         float cell, int64_t max_cells, BatchGrid* out, hipStream_t s) {
+    const int n = seg_off_host[n_seg];
+    float* bbox; SegGrid* seg; int* total;
+    IBL_ARENA(bbox, float, (int64_t)n_seg * 6 + 6);
+    IBL_ARENA(seg, SegGrid, n_seg + 1);
+    IBL_ARENA(total, int, 4);
+    out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
+    out->tile_base = nullptr; out->n_tiles = 0; out->ts = 0;
+    if (n_seg == 0) return IBL_OK;
+    hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox);
+    IBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ibl_grid_dims_kernel, dim3(1), dim3(256), 0, s, bbox, n_seg, cell, (long long)max_cells, seg, total,
+                       ctx->d_status);
+    IBL_LAUNCH_CHECK();
+    int h_total = 0;
+    IBL_HIP_CHECK(hipMemcpyAsync(&h_total, total, sizeof(int), hipMemcpyDeviceToHost, s));
+    IBL_HIP_CHECK(hipStreamSynchronize(s));     // the table size decides the scan length (one small read-back per grid)
+    if (h_total <= 0 || h_total > max_cells) return ibl_set_error(IBL_ERR_OVERFLOW, "grid: %d cells exceed the budget %lld", h_total, (long long)max_cells);
+    return grid_fill(ctx, pts, seg_off_dev, n_seg, n, seg, h_total, out, s);
+}
+
+double ibl_knn_safety() {
+    static const double v = [] { const char* e = getenv("IBL_KNN_SAFETY"); return e ? atof(e) : 1.0; }();
+    return v;
+}
+int ibl_knn_rho() {
+    static const int v = [] { const char* e = getenv("IBL_KNN_RHO"); const int r = e ? atoi(e) : 3; return r < 1 ? 1 : (r > 4 ? 4 : r); }();
+    return v;
+}
+
+int ibl_stage_upload(ibl_reg_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes, hipStream_t s) {
+    if (bytes <= 0) return IBL_OK;
+    const int64_t need = ibl_align_up(bytes, 64);
+    if (ctx->pin && ctx->pin_used + need <= ctx->pin_size) {
+        unsigned char* p = ctx->pin + ctx->pin_used;
+        ctx->pin_used += need;
+        memcpy(p, src_host, (size_t)bytes);
+        IBL_HIP_CHECK(hipMemcpyAsync(dst_dev, p, (size_t)bytes, hipMemcpyHostToDevice, s));
+        return IBL_OK;
+    }
+    IBL_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, s));
+    IBL_HIP_CHECK(hipStreamSynchronize(s));      // staging exhausted: the caller's buffer may die after this call
+    return IBL_OK;
+}
+
+int ibl_build_tile_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
+                        const float* bbox_host, double radius, int max_nn, int ts, int64_t max_cells, BatchGrid* out, hipStream_t s) {
+    const int n = seg_off_host[n_seg];
+    SegGrid* seg; int* tile_base;
+    IBL_ARENA(seg, SegGrid, n_seg + 1);
+    IBL_ARENA(tile_base, int, n_seg + 2);
+    out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
+    out->tile_base = tile_base; out->n_tiles = 0; out->ts = ts;
+    if (n_seg == 0) return IBL_OK;
+    std::vector<SegGrid> h(n_seg);
+    std::vector<int> tb(n_seg + 1, 0);
+    const double safety = ibl_knn_safety(), rho_t = (double)ibl_knn_rho();
+    long long cells = 0, tiles = 0;
+    for (int sgi = 0; sgi < n_seg; ++sgi) {
+        const float* b = bbox_host + 6 * (size_t)sgi;
+        const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+        const int cnt = seg_off_host[sgi + 1] - seg_off_host[sgi];
+        // mean surface density from the faces of the box; a ball of `rho` cells should hold safety x max_nn points
+        const double area = 2.0 * ((double)ex * ey + (double)ey * ez + (double)ez * ex);
+        double c = radius;
+        if (cnt > 0 && area > 0) {
+            const double dens = (double)cnt / area;
+            c = sqrt(safety * (double)max_nn / (3.141592653589793 * rho_t * rho_t * dens));
+        }
+        if (c > radius) c = radius;
+        if (c < radius / 12.0) c = radius / 12.0;
+        float cf = (float)c;
+        const float emax = fmaxf(ex, fmaxf(ey, ez));
+        if (emax / 128.0f > cf) cf = emax / 128.0f;     // bound the table: at most ~129 cells per axis
+        SegGrid g;
+        g.minx = b[0]; g.miny = b[1]; g.minz = b[2];
+        g.inv = 1.0f / cf;
+        g.nx = (int)floorf(ex * g.inv) + 1;
+        g.ny = (int)floorf(ey * g.inv) + 1;
+        g.nz = (int)floorf(ez * g.inv) + 1;
+        if (cells + (long long)g.nx * g.ny * g.nz > max_cells) { g.nx = g.ny = g.nz = 1; }      // budget: one cell (slow, correct)
+        g.cell_base = (int)cells;
+        cells += (long long)g.nx * g.ny * g.nz;
+        h[sgi] = g;
+        tb[sgi] = (int)tiles;
+        tiles += (long long)((g.nx + ts - 1) / ts) * ((g.ny + ts - 1) / ts) * ((g.nz + ts - 1) / ts);
+        if (tiles > 0x7fff0000ll) return ibl_set_error(IBL_ERR_OVERFLOW, "tile grid: too many tiles");
+    }
+    tb[n_seg] = (int)tiles;
+    out->n_tiles = (int)tiles;
+    int st = ibl_stage_upload(ctx, seg, h.data(), sizeof(SegGrid) * (int64_t)n_seg, s);
+    if (st) return st;
+    st = ibl_stage_upload(ctx, tile_base, tb.data(), sizeof(int) * (int64_t)(n_seg + 1), s);
+    if (st) return st;
+    return grid_fill(ctx, pts, seg_off_dev, n_seg, n, seg, (int)cells, out, s);
 }

@@ -16,9 +16,16 @@
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
 #include "reg_common.h"
 
 #define KNN_BINS 256
+#ifndef KNN_ROWS
+#define KNN_ROWS 8        // candidate rows whose first 64 points are in flight together
+#endif
 #define KNN_CAPB 256
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -34,6 +41,36 @@ struct WaveLds {
     int scratch[64];
     int sel_j[256];          // consumers that do heavy per-neighbour work first compact the selected set here
     float sel_d2[256];
+};
+
+// A selected candidate is handed to the consumers as a HANDLE; the accessor turns it into the point and its original index.
+//   GlobalAcc: handle = position in the cell-sorted point array (the per-query walk over the grid, hybrid_select)
+//   TileAcc:   handle = slot of the workgroup's LDS-staged neighbourhood (tile_select)
+struct GlobalAcc {
+    const float4* sorted;
+    const int* order;
+    __device__ __forceinline__ float4 pt(int h) const { return sorted[h]; }
+    __device__ __forceinline__ int ord(int h) const { return order[h]; }
+};
+struct TileAcc {
+    const float4* pts;       // LDS
+    const int* ordl;         // LDS
+    __device__ __forceinline__ float4 pt(int h) const { return pts[h]; }
+    __device__ __forceinline__ int ord(int h) const { return ordl[h]; }
+};
+
+// LDS-staged neighbourhood of one tile (a cube of ts^3 cells): every point of the cube of `rho` cells around the tile, copied once
+// per workgroup and searched by all the tile's queries
+#define KT_ROWS 144          // candidate rows (z, y) of the staging cube: (ts + 2 rho)^2 <= 144
+template <int KT_CAP>        // staged candidates
+struct TileLds {
+    static constexpr int CAP = KT_CAP;
+    float4 pts[KT_CAP];
+    int ord[KT_CAP];
+    int row_b[KT_ROWS];
+    int row_off[KT_ROWS + 1];
+    int q_b[16];
+    int q_off[17];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -87,7 +124,7 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
     };
     // A wave's walk is a chain of dependent latencies (row bounds -> points -> next row), and these kernels are bound by it, so the
     // bounds of 64 rows are fetched in one step (lane r holds row r), empty rows are dropped by ballot, and the first 64 points of
-    // three rows at a time are in flight together.
+    // KNN_ROWS rows at a time are in flight together.
     auto scan = [&](auto&& f) {
         for (int rc = 0; rc < nrows; rc += 64) {
             int cb = my_b, ce = my_e;
@@ -102,10 +139,10 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
             }
             unsigned long long live = __ballot(ce > cb);
             while (live) {
-                int b[3], e[3];
-                float4 p[3];
+                int b[KNN_ROWS], e[KNN_ROWS];
+                float4 p[KNN_ROWS];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < KNN_ROWS; ++u) {
                     const bool have = live != 0ull;
                     const int r = have ? __ffsll((long long)live) - 1 : 0;
                     if (have) live &= live - 1ull;
@@ -114,7 +151,7 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
                     p[u] = b[u] + lane < e[u] ? g.sorted_pts[b[u] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < KNN_ROWS; ++u) {
                     for (int jb = b[u]; jb < e[u]; jb += 64) {
                         const int j = jb + lane;
                         float4 q4 = p[u];
@@ -218,15 +255,13 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
                 const unsigned mid = lo + ((hi - lo) >> 1);
                 int c = 0;
 #pragma unroll
-                for (int t = 0; t < KNN_CAPB / 64; ++t) c += (ev[t] && eb[t] <= mid) ? 1 : 0;
-                c = wave_sum_i(c);
+                for (int t = 0; t < KNN_CAPB / 64; ++t) c += __popcll(__ballot(ev[t] && eb[t] <= mid));
                 if (c >= need) hi = mid; else lo = mid + 1;
             }
             const unsigned T = lo;
             int cl = 0, ct = 0;
 #pragma unroll
-            for (int t = 0; t < KNN_CAPB / 64; ++t) { cl += (ev[t] && eb[t] < T) ? 1 : 0; ct += (ev[t] && eb[t] == T) ? 1 : 0; }
-            cl = wave_sum_i(cl); ct = wave_sum_i(ct);
+            for (int t = 0; t < KNN_CAPB / 64; ++t) { cl += __popcll(__ballot(ev[t] && eb[t] < T)); ct += __popcll(__ballot(ev[t] && eb[t] == T)); }
             const int need2 = need - cl;
             int I = 0x7FFFFFFF;
             if (ct > need2) {
@@ -235,8 +270,7 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
                     const int mid = ilo + ((ihi - ilo) >> 1);
                     int c = 0;
 #pragma unroll
-                    for (int t = 0; t < KNN_CAPB / 64; ++t) c += (ev[t] && eb[t] == T && ei[t] <= mid) ? 1 : 0;
-                    c = wave_sum_i(c);
+                    for (int t = 0; t < KNN_CAPB / 64; ++t) c += __popcll(__ballot(ev[t] && eb[t] == T && ei[t] <= mid));
                     if (c >= need2) ihi = mid; else ilo = mid + 1;
                 }
                 I = ilo;
@@ -404,11 +438,16 @@ __device__ inline void fast_eigen_normal_d(const double* cov, double* n) {
 // of the grid a cloud was enumerated from: features of an instance computed on its own (ibl_instance_features_batch)
 // are bit-identical to those computed inside a concatenation whose other instances are out of reach.
 // in: L->sel_j[0..k) (+ sel_d2); out: L->b_j[0..k) (+ b_bits = d2 bits) in ascending order[j].
-template <bool WITH_D2>
-__device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const int* __restrict__ order, int k) {
+template <bool WITH_D2, class Acc>
+__device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const Acc& acc, int k) {
     const int lane = threadIdx.x & 63;
     wave_lds_sync();
-    for (int t = lane; t < k; t += 64) L->b_idx[t] = order[L->sel_j[t]];
+#ifdef KNN_LAB_NO_SORT
+    for (int t = lane; t < k; t += 64) { L->b_j[t] = L->sel_j[t]; if (WITH_D2) L->b_bits[t] = __float_as_uint(L->sel_d2[t]); }
+    wave_lds_sync();
+    return;
+#endif
+    for (int t = lane; t < k; t += 64) L->b_idx[t] = acc.ord(L->sel_j[t]);
     wave_lds_sync();
     for (int t = lane; t < k; t += 64) {
         const int key = L->b_idx[t];
@@ -419,10 +458,10 @@ __device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const int* __
     }
     wave_lds_sync();
 }
+template <class Acc>
 struct NormalConsumer {
     float4* normals;
-    const int* order;
-    const float4* sorted;
+    Acc acc;
     WaveLds* L;
     int qi;
     int ncount;
@@ -435,11 +474,11 @@ struct NormalConsumer {
     }
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
-        sort_selected_by_index<false>(L, order, k);
+        sort_selected_by_index<false>(L, acc, k);
         double c[9];
         for (int t = 0; t < 9; ++t) c[t] = 0.0;
         for (int t = lane; t < k; t += 64) {
-            const float4 p = sorted[L->b_j[t]];
+            const float4 p = acc.pt(L->b_j[t]);
             const double x = p.x, y = p.y, z = p.z;
             c[0] += x; c[1] += y; c[2] += z;
             c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
@@ -490,10 +529,10 @@ __device__ inline void pair_features_d(const float4& p1, const float4& n1f, cons
 
 __device__ __forceinline__ int clamp_bin11(int h) { return h < 0 ? 0 : (h >= 11 ? 10 : h); }
 
+template <class Acc>
 struct SpfhConsumer {
     const float4* normals;   // original order
-    const int* order;
-    const float4* sorted;    // cell-sorted points
+    Acc acc;
     unsigned char* spfh_cnt; // [N][36] integer SPFH histograms
     int* nbr_idx;            // [N][K]
     float* nbr_d2;           // [N][K]
@@ -524,15 +563,19 @@ struct SpfhConsumer {
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
         int* hist = L->scratch;
-        sort_selected_by_index<true>(L, order, k);
+        sort_selected_by_index<true>(L, acc, k);
         for (int t = lane; t < k; t += 64) {
             const int j = L->b_j[t];
-            const int jo = order[j];
+            const int jo = acc.ord(j);
             nbr_idx[(int64_t)qi * K + t] = jo;
             nbr_d2[(int64_t)qi * K + t] = __uint_as_float(L->b_bits[t]);
             if (jo != qi) {
                 double f[3];
-                pair_features_d(q, qn, sorted[j], normals[jo], f);
+#ifdef KNN_LAB_NO_PAIR
+                f[0] = (double)jo * 1e-9; f[1] = 0.1; f[2] = 0.2;
+#else
+                pair_features_d(q, qn, acc.pt(j), normals[jo], f);
+#endif
                 atomicAdd(&hist[clamp_bin11((int)floor(11 * (f[0] + M_PI) / (2.0 * M_PI)))], 1);
                 atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
                 atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
@@ -546,10 +589,10 @@ struct SpfhConsumer {
     }
 };
 
+template <class Acc>
 struct GradConsumer {
     const float4* normals;
-    const int* order;
-    const float4* sorted;
+    Acc acc;
     float4* grad;
     int qi;
     float4 q, qn;
@@ -564,13 +607,13 @@ struct GradConsumer {
     }
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
-        sort_selected_by_index<false>(L, order, k);
+        sort_selected_by_index<false>(L, acc, k);
         double a[9];             // AtA (6 unique: 00 01 02 11 12 22) + Atb (3)
         for (int t = 0; t < 9; ++t) a[t] = 0.0;
         for (int t = lane; t < k; t += 64) {
             const int j = L->b_j[t];
-            if (order[j] == qi) continue;
-            const float4 p = sorted[j];
+            if (acc.ord(j) == qi) continue;
+            const float4 p = acc.pt(j);
             const double vt[3] = {q.x, q.y, q.z}, nt[3] = {qn.x, qn.y, qn.z};
             const double dd[3] = {(double)p.x - vt[0], (double)p.y - vt[1], (double)p.z - vt[2]};
             const double pr = dot3d(dd, nt);
@@ -607,32 +650,300 @@ struct GradConsumer {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ibl_normals_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ seg_off,
-                                                          float radius, float r2, int max_nn, float4* __restrict__ normals, int* status) {
-    __shared__ WaveLds lds[4];
-    const int n = seg_off[g.n_seg];
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= n) return;
-    const int s = seg_of(seg_off, g.n_seg, qi);
-    NormalConsumer cons;
-    cons.normals = normals; cons.qi = qi; cons.order = g.order; cons.sorted = g.sorted_pts; cons.L = &lds[threadIdx.x >> 6];
-    hybrid_select(g, g.seg[s], pts[qi], qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
+// ---- the search on an LDS-staged neighbourhood ---------------------------------------------------------------------------------
+// One wavefront, one query, `total` candidates in T (every point of the staging cube).  cover2 = squared distance from the query to
+// the nearest face of the staging cube (INFINITY when the cube reaches past the search radius or the cloud's bounds on every side):
+// all points closer than that are staged, so once max_nn of them are, the staged k nearest are the cloud's k nearest.  Returns
+// false -- before any consumer call -- when that cannot be shown or the boundary bin overflows its list; the caller then runs
+// hybrid_select for the query.  Selection rule and tie order (d2 bits, then original index) are those of hybrid_select.
+template <class TL, class Consumer>
+__device__ bool tile_select(const TL& T, int total, const float4 q, float cover2, float r2, int max_nn, WaveLds* L, Consumer& cons) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float bscale = (float)KNN_BINS / r2;
+    auto bin_of = [&](float d2) { int b = (int)(d2 * bscale); return b > KNN_BINS - 1 ? KNN_BINS - 1 : b; };
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 64; ++t) L->hist[lane * (KNN_BINS / 64) + t] = 0;
+    wave_lds_sync();
+    int in_ball = 0;
+#pragma unroll 1
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        const float4 p = T.pts[t < total ? t : 0];
+        const float d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
+        const bool in = t < total && d2 < r2;
+        if (in) atomicAdd(&L->hist[bin_of(d2)], 1);
+        in_ball += __popcll(__ballot(in && d2 < cover2));
+    }
+    wave_lds_sync();
+    int hb[KNN_BINS / 64];
+    int s = 0;
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 64; ++t) { hb[t] = L->hist[lane * (KNN_BINS / 64) + t]; s += hb[t]; }
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const int cnt = __shfl(incl, 63, 64);
+    if (cover2 != INFINITY && in_ball < max_nn) return false;
+    const int excl = incl - s;
+    const int k = cnt < max_nn ? cnt : max_nn;
+    const bool select_all = cnt <= max_nn;
+    int bstar = KNN_BINS, n_below = 0, pop = 0;
+    if (!select_all) {
+        const unsigned long long m = __ballot(incl >= max_nn);
+        const int Lc = __ffsll((long long)m) - 1;
+        int bin_here = 0, my_below = 0, my_pop = 0;
+        int run = excl;
+#pragma unroll
+        for (int t = 0; t < KNN_BINS / 64; ++t) {
+            if (my_pop == 0 && run + hb[t] >= max_nn) { bin_here = lane * (KNN_BINS / 64) + t; my_below = run; my_pop = hb[t]; }
+            run += hb[t];
+        }
+        bstar = __shfl(bin_here, Lc, 64);
+        n_below = __shfl(my_below, Lc, 64);
+        pop = __shfl(my_pop, Lc, 64);
+        if (pop > KNN_CAPB) return false;
+    }
+    cons.begin(k);
+    int bcount = 0;
+    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        const float4 p = T.pts[t < total ? t : 0];
+        const float d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);        // the same bits as in pass 1
+        const bool in = t < total && d2 < r2;
+        const int b = in ? bin_of(d2) : KNN_BINS;
+        cons.accept(in && (select_all || b < bstar), t, none, d2);
+        if (!select_all) {
+            const bool park = in && b == bstar;
+            const unsigned long long m = __ballot(park);
+            if (park) {
+                const int pos = bcount + __popcll(m & lt_mask);
+                L->b_bits[pos] = __float_as_uint(d2);
+                L->b_idx[pos] = T.ord[t];
+                L->b_j[pos] = t;
+            }
+            bcount += __popcll(m);
+        }
+    }
+    if (!select_all) {
+        // the boundary bin: an entry is selected when fewer than `need` entries precede it in (d2 bits, original index) order
+        const int need = max_nn - n_below;
+        wave_lds_sync();
+        for (int e0 = 0; e0 < pop; e0 += 64) {
+            const int e = e0 + lane;
+            const bool v = e < pop;
+            const unsigned mb = v ? L->b_bits[e] : 0xFFFFFFFFu;
+            const int mi = v ? L->b_idx[e] : 0x7FFFFFFF;
+            int rank = 0;
+            for (int u = 0; u < pop; ++u) {
+                const unsigned ub = L->b_bits[u];
+                const int ui = L->b_idx[u];
+                rank += (ub < mb || (ub == mb && ui < mi)) ? 1 : 0;
+            }
+            const bool sel = v && rank < need;
+            cons.accept(sel, v ? L->b_j[e] : 0, none, __uint_as_float(mb));
+        }
+    }
+    cons.finish(k);
+    return true;
 }
 
-__global__ __launch_bounds__(256) void ibl_spfh_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
-                                                       const int* __restrict__ seg_off, float radius, float r2, int max_nn,
-                                                       unsigned char* __restrict__ spfh_cnt, int* __restrict__ nbr_idx, float* __restrict__ nbr_d2,
-                                                       int* __restrict__ nbr_cnt, int* status) {
+// Workgroup per tile: stage the neighbourhood, then every wavefront takes queries of the tile in turn.  need_pop[rho] = candidates
+// the staging cube of reach rho should hold for the ball inside it to contain max_nn of them (host: 1.15 max_nn (ts + 2 rho)^2 /
+// (pi rho^2)); the reach grows from 2 until it does, the cube fills the LDS budget or covers the whole radius.
+struct NeedPop { float v[8]; int rho_start; };
+
+template <int TS, class TL, class Factory>
+__device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int max_nn, const NeedPop& need_pop, int* __restrict__ fb_list,
+                               int* __restrict__ fb_count, const Factory& fac, int q_lo, int q_hi, TL& T, WaveLds* wl) {
+    constexpr int KT_CAP = TL::CAP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    if (tile >= g.n_tiles) return;
+    int lo = 0, hi = g.n_seg;                      // the segment whose tile range holds `tile`
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (g.tile_base[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const SegGrid sg = g.seg[lo];
+    const int ntx = (sg.nx + TS - 1) / TS, nty = (sg.ny + TS - 1) / TS;
+    int tt = tile - g.tile_base[lo];
+    const int tx = tt % ntx; tt /= ntx;
+    const int ty = tt % nty, tz = tt / nty;
+    const int cx0 = tx * TS, cx1 = min(cx0 + TS, sg.nx) - 1;
+    const int cy0 = ty * TS, cy1 = min(cy0 + TS, sg.ny) - 1;
+    const int cz0 = tz * TS, cz1 = min(cz0 + TS, sg.nz) - 1;
+    // the tile's queries: runs of the cell-sorted array, one per (z, y) row of the tile
+    const int qny = cy1 - cy0 + 1, qrows = qny * (cz1 - cz0 + 1);
+    if (tid < qrows) {
+        const int row = sg.cell_base + ((cz0 + tid / qny) * sg.ny + cy0 + tid % qny) * sg.nx;
+        const int b = g.cell_start[row + cx0];
+        T.q_b[tid] = b;
+        T.q_off[tid + 1] = g.cell_start[row + cx1 + 1] - b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        T.q_off[0] = 0;
+        for (int r = 0; r < qrows; ++r) { acc += T.q_off[r + 1]; T.q_off[r + 1] = acc; }
+    }
+    __syncthreads();
+    const int nq = T.q_off[qrows];
+    if (nq == 0) return;
+
+    int reach_max = (int)ceilf(radius * sg.inv);
+    if (reach_max < 1) reach_max = 1;
+    const int rho_cap = min(reach_max, TS <= 2 ? 5 : 4);            // (TS + 2 rho)^2 <= KT_ROWS
+    int rho = min(need_pop.rho_start, rho_cap);
+    int x0, x1, y0, y1, z0, z1, total = 0;
+    bool staged = false, final_try = false;
+    for (int it = 0; it < 8; ++it) {
+        x0 = max(cx0 - rho, 0); x1 = min(cx1 + rho, sg.nx - 1);
+        y0 = max(cy0 - rho, 0); y1 = min(cy1 + rho, sg.ny - 1);
+        z0 = max(cz0 - rho, 0); z1 = min(cz1 + rho, sg.nz - 1);
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        __syncthreads();                              // row tables of the previous attempt are no longer read
+        if (tid < nrows) {
+            const int row = sg.cell_base + ((z0 + tid / ny) * sg.ny + y0 + tid % ny) * sg.nx;
+            const int b = g.cell_start[row + x0];
+            T.row_b[tid] = b;
+            T.row_off[tid + 1] = g.cell_start[row + x1 + 1] - b;
+        }
+        __syncthreads();
+        if (wave == 0) {                              // exclusive prefix of <= 144 row lengths: three per lane + a wave scan
+            int v[3], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { const int r = 3 * lane + u; v[u] = r < nrows ? T.row_off[r + 1] : 0; sum += v[u]; }
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            int run = incl - sum;
+            if (lane == 0) T.row_off[0] = 0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { const int r = 3 * lane + u; run += v[u]; if (r < nrows) T.row_off[r + 1] = run; }
+        }
+        __syncthreads();
+        total = T.row_off[nrows];
+        if (total > KT_CAP) {
+            if (rho > 1 && !final_try) { --rho; final_try = true; continue; }
+            break;                                     // does not fit at any reach: every query takes the global walk
+        }
+        if (final_try || rho >= rho_cap || (float)total >= need_pop.v[rho]) { staged = true; break; }
+        ++rho;
+    }
+    const float cellw = 1.0f / sg.inv;
+    if (staged) {
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        for (int t = tid; t < total; t += 256) {
+            int a = 0, b = nrows;                      // the row r with row_off[r] <= t < row_off[r + 1]
+            while (b - a > 1) {
+                const int mid = (a + b) >> 1;
+                if (T.row_off[mid] <= t) a = mid; else b = mid;
+            }
+            const int j = T.row_b[a] + (t - T.row_off[a]);
+            T.pts[t] = g.sorted_pts[j];
+            T.ord[t] = g.order[j];
+        }
+    }
+    __syncthreads();
+    // faces of the staging cube (none where it reaches the cloud's bounds: nothing lies beyond), pulled in by the rounding margin of
+    // the cell index
+    const float mgn = 1e-3f * cellw;
+    const float fx0 = x0 > 0 ? sg.minx + (float)x0 * cellw + mgn : -INFINITY, fx1 = x1 < sg.nx - 1 ? sg.minx + (float)(x1 + 1) * cellw - mgn : INFINITY;
+    const float fy0 = y0 > 0 ? sg.miny + (float)y0 * cellw + mgn : -INFINITY, fy1 = y1 < sg.ny - 1 ? sg.miny + (float)(y1 + 1) * cellw - mgn : INFINITY;
+    const float fz0 = z0 > 0 ? sg.minz + (float)z0 * cellw + mgn : -INFINITY, fz1 = z1 < sg.nz - 1 ? sg.minz + (float)(z1 + 1) * cellw - mgn : INFINITY;
+    WaveLds* L = &wl[wave];
+    int run_r = 0;
+    for (int qk = wave; qk < nq; qk += 4) {
+        while (qk >= T.q_off[run_r + 1]) ++run_r;
+        const int jq = T.q_b[run_r] + (qk - T.q_off[run_r]);
+        const int qi = g.order[jq];
+        if (qi < q_lo || qi >= q_hi) continue;
+        const float4 q = g.sorted_pts[jq];
+        bool done = false;
+        if (staged) {
+            float cover = fminf(fminf(q.x - fx0, fx1 - q.x), fminf(fminf(q.y - fy0, fy1 - q.y), fminf(q.z - fz0, fz1 - q.z)));
+            if (cover < 0.f) cover = 0.f;
+            const float cover2 = cover >= radius ? INFINITY : cover * cover;
+            auto cons = fac.template make<TileAcc>(qi, q, L, TileAcc{T.pts, T.ord});
+            done = tile_select(T, total, q, cover2, r2, max_nn, L, cons);
+        }
+        // not provable from the staged cube (sparse spot, LDS budget, boundary-bin overflow): the query joins the list of the
+        // per-query grid walk that runs after this kernel (ibl_knn_list_kernel)
+        if (!done && lane == 0) fb_list[atomicAdd(fb_count, 1)] = jq;
+    }
+}
+
+struct NormalFactory {
+    float4* normals;
+    template <class Acc> __device__ NormalConsumer<Acc> make(int qi, const float4&, WaveLds* L, const Acc& acc) const {
+        NormalConsumer<Acc> c;
+        c.normals = normals; c.acc = acc; c.L = L; c.qi = qi; c.ncount = 0;
+        return c;
+    }
+};
+struct SpfhFactory {
+    const float4* normals; unsigned char* spfh_cnt; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K;
+    template <class Acc> __device__ SpfhConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc) const {
+        SpfhConsumer<Acc> c;
+        c.normals = normals; c.acc = acc; c.spfh_cnt = spfh_cnt; c.nbr_idx = nbr_idx; c.nbr_d2 = nbr_d2; c.nbr_cnt = nbr_cnt; c.K = K;
+        c.qi = qi; c.q = q; c.qn = normals[qi]; c.L = L; c.ncount = 0;
+        return c;
+    }
+};
+struct GradFactory {
+    const float4* normals; float4* grad;
+    template <class Acc> __device__ GradConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc) const {
+        GradConsumer<Acc> c;
+        c.normals = normals; c.acc = acc; c.grad = grad; c.qi = qi; c.q = q; c.qn = normals[qi]; c.L = L; c.ncount = 0;
+        return c;
+    }
+};
+
+// tiles: one workgroup each
+template <int TS, int CAP, class Factory>
+__global__ __launch_bounds__(256) void ibl_knn_tile_kernel(BatchGrid g, float radius, float r2, int max_nn, NeedPop need_pop, Factory fac,
+                                                           int q_lo, int q_hi, int* __restrict__ fb_list, int* __restrict__ fb_count) {
+    __shared__ TileLds<CAP> T;
+    __shared__ WaveLds wl[4];
+    tile_knn_block<TS>(g, radius, r2, max_nn, need_pop, fb_list, fb_count, fac, q_lo, q_hi, T, wl);
+}
+
+// the queries the tile kernel could not answer from its staged cubes: one wavefront each, walking the grid (sorted positions in list)
+template <class Factory>
+__global__ __launch_bounds__(256) void ibl_knn_list_kernel(BatchGrid g, const int* __restrict__ seg_off, float radius, float r2, int max_nn,
+                                                           Factory fac, const int* __restrict__ list, const int* __restrict__ count, int* status) {
     __shared__ WaveLds lds[4];
-    const int n = seg_off[g.n_seg];
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= n) return;
+    const int n = *count;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+        const int jq = list[e];
+        const int qi = g.order[jq];
+        const float4 q = g.sorted_pts[jq];
+        const int s = seg_of(seg_off, g.n_seg, qi);
+        auto cons = fac.template make<GlobalAcc>(qi, q, &lds[threadIdx.x >> 6], GlobalAcc{g.sorted_pts, g.order});
+        hybrid_select(g, g.seg[s], q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
+    }
+}
+
+// no tiles (grids of ibl_build_batch_grid): one wavefront per query walks the grid
+template <class Factory>
+__global__ __launch_bounds__(256) void ibl_knn_query_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ seg_off,
+                                                            float radius, float r2, int max_nn, Factory fac, int q0, int q1, int* status) {
+    __shared__ WaveLds lds[4];
+    const int qi = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= q1) return;
     const int s = seg_of(seg_off, g.n_seg, qi);
-    SpfhConsumer cons;
-    cons.normals = normals; cons.order = g.order; cons.spfh_cnt = spfh_cnt; cons.nbr_idx = nbr_idx; cons.nbr_d2 = nbr_d2;
-    cons.nbr_cnt = nbr_cnt; cons.K = max_nn; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
-    cons.L = &lds[threadIdx.x >> 6]; cons.sorted = g.sorted_pts;
-    hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
+    const float4 q = pts[qi];
+    auto cons = fac.template make<GlobalAcc>(qi, q, &lds[threadIdx.x >> 6], GlobalAcc{g.sorted_pts, g.order});
+    hybrid_select(g, g.seg[s], q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
 }
 
 // Position of histogram bin b in the "matching order" of the feature search (reg_register.hip, oracle_reg.c FEAT_ORDER: the
@@ -685,7 +996,9 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
             for (int r = 0; r < m; ++r) {
                 const double dist = T.dist[r];
                 if (dist <= 0.0) continue;
-                const float sp = (float)((double)T.cnt[r][b] * T.inc[r]);
+                const unsigned cb = T.cnt[r][b];
+                if (cb == 0) continue;                        // an empty bin adds an exact zero
+                const float sp = (float)((double)cb * T.inc[r]);
                 acc += (double)sp / dist;
             }
             wave_lds_sync();
@@ -703,19 +1016,6 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
         }
         fpfh[(int64_t)qi * 33 + (matching_order ? FEAT_POS[lane] : lane)] = out;
     }
-}
-
-__global__ __launch_bounds__(256) void ibl_color_grad_kernel(BatchGrid g, const float4* __restrict__ pts, const float4* __restrict__ normals,
-                                                             const int* __restrict__ seg_off, int q0, int q1, float radius, float r2,
-                                                             int max_nn, float4* __restrict__ grad, int* status) {
-    __shared__ WaveLds lds[4];
-    const int qi = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= q1) return;
-    const int s = seg_of(seg_off, g.n_seg, qi);
-    GradConsumer cons;
-    cons.normals = normals; cons.order = g.order; cons.sorted = g.sorted_pts; cons.grad = grad; cons.qi = qi; cons.q = pts[qi]; cons.qn = normals[qi];
-    cons.L = &lds[threadIdx.x >> 6];
-    hybrid_select(g, g.seg[s], cons.q, qi, radius, r2, max_nn, &lds[threadIdx.x >> 6], cons, status);
 }
 
 // radius outlier: keep[i] = (#points with d2 < r2, self included) > nb_points.  Thread per point, early exit.
@@ -746,40 +1046,79 @@ __global__ __launch_bounds__(256) void ibl_radius_count_kernel(BatchGrid g, cons
 // ------------------------------------------------------------------------------------------------
 // host launchers (used by reg_api.hip)
 // ------------------------------------------------------------------------------------------------
-int ibl_launch_normals(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
-                       int* status, hipStream_t s) {
-    if (n <= 0) return IBL_OK;
-    if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "normals: max_nn %d > 256", max_nn);
-    hipLaunchKernelGGL(ibl_normals_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, seg_off, (float)radius,
-                       (float)(radius * radius), max_nn, normals, status);
+static NeedPop need_pop_table(int max_nn, int ts) {
+    NeedPop np;
+    np.v[0] = 0.f;
+    for (int rho = 1; rho < 8; ++rho)
+        np.v[rho] = (float)(ibl_knn_safety() * max_nn * (ts + 2.0 * rho) * (ts + 2.0 * rho) / (3.14159265358979 * rho * rho));
+    np.rho_start = ibl_knn_rho();
+    return np;
+}
+
+template <class Factory>
+static int launch_knn(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const int* seg_off, int n, int q0, int q1, double radius, int max_nn,
+                      const Factory& fac, int* status, hipStream_t s) {
+    if (q1 <= q0) return IBL_OK;
+    const float r = (float)radius, r2 = (float)(radius * radius);
+    if (g.tile_base && g.n_tiles > 0) {
+        ArenaMark m(ctx);                    // (released on return: later allocations are used by later kernels of the same stream)
+        int *fb_list, *fb_count;
+        IBL_ARENA(fb_list, int, (int64_t)n + 64);
+        IBL_ARENA(fb_count, int, 64);
+        IBL_HIP_CHECK(hipMemsetAsync(fb_count, 0, sizeof(int), s));
+        const NeedPop np = need_pop_table(max_nn, g.ts);
+        // LDS budget of the staged cube: 20 B per candidate.  The 100-neighbour search (tiles of 2^3 cells) stages up to 2 560 points
+        // (77 KiB per workgroup with the four waves' selection scratch: two workgroups per CU), the 30-neighbour ones 1 024
+        if (g.ts == 2) hipLaunchKernelGGL((ibl_knn_tile_kernel<2, 2560, Factory>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
+        else if (g.ts == 4) hipLaunchKernelGGL((ibl_knn_tile_kernel<4, 1024, Factory>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
+        else return ibl_set_error(IBL_ERR_INTERNAL, "k-NN tiles of %d^3 cells are not built", g.ts);
+        IBL_LAUNCH_CHECK();
+        const int blocks = std::max(1, std::min(2048, (q1 - q0 + 3) / 4));
+        hipLaunchKernelGGL((ibl_knn_list_kernel<Factory>), dim3(blocks), dim3(256), 0, s, g, seg_off, r, r2, max_nn, fac, fb_list, fb_count, status);
+        if (getenv("IBL_KNN_DEBUG")) {                      // diagnostics: how many queries the staged cubes could not answer
+            int h = 0;
+            (void)hipMemcpyAsync(&h, fb_count, sizeof(int), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "[knn] r=%.3f k=%d ts=%d tiles=%d queries=%d fallback=%d (%.1f %%)\n", radius, max_nn, g.ts, g.n_tiles, q1 - q0, h, 100.0 * h / (q1 - q0));
+        }
+    } else {
+        hipLaunchKernelGGL((ibl_knn_query_kernel<Factory>), dim3((q1 - q0 + 3) / 4), dim3(256), 0, s, g, pts, seg_off, r, r2, max_nn, fac, q0, q1, status);
+    }
     IBL_LAUNCH_CHECK();
     return IBL_OK;
 }
 
-int ibl_launch_fpfh(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
+int ibl_launch_normals(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int max_nn, float4* normals,
+                       int* status, hipStream_t s) {
+    if (n <= 0) return IBL_OK;
+    if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "normals: max_nn %d > 256", max_nn);
+    void* tok;
+    ibl_prof_begin(IBL_PROF_NORMALS, 24.0 * (double)n, s, &tok);
+    const int st = launch_knn(ctx, g, pts, seg_off, n, 0, n, radius, max_nn, NormalFactory{normals}, status, s);
+    ibl_prof_end(tok, s);
+    return st;
+}
+
+int ibl_launch_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int n, double radius, int max_nn,
                     unsigned char* spfh, int* nbr_idx, float* nbr_d2, int* nbr_cnt, float* fpfh, int matching_order, int* status,
                     hipStream_t s) {
     if (n <= 0) return IBL_OK;
     if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "fpfh: max_nn %d > 256 (SPFH histograms are stored as bytes)", max_nn);
     void* tok;
     ibl_prof_begin(IBL_PROF_SPFH, 156.0 * (double)n, s, &tok);
-    hipLaunchKernelGGL(ibl_spfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, (float)radius,
-                       (float)(radius * radius), max_nn, spfh, nbr_idx, nbr_d2, nbr_cnt, status);
+    const int st = launch_knn(ctx, g, pts, seg_off, n, 0, n, radius, max_nn, SpfhFactory{normals, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn}, status, s);
     ibl_prof_end(tok, s);
-    IBL_LAUNCH_CHECK();
+    if (st) return st;
     hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, matching_order, fpfh);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
 }
 
-int ibl_launch_color_grad(const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
+int ibl_launch_color_grad(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
                           int max_nn, float4* grad, int* status, hipStream_t s) {
     if (q1 <= q0) return IBL_OK;
     if (max_nn > 256) return ibl_set_error(IBL_ERR_UNSUPPORTED, "colour gradient: max_nn %d > 256", max_nn);
-    hipLaunchKernelGGL(ibl_color_grad_kernel, dim3((q1 - q0 + 3) / 4), dim3(256), 0, s, g, pts, normals, seg_off, q0, q1, (float)radius,
-                       (float)(radius * radius), max_nn, grad, status);
-    IBL_LAUNCH_CHECK();
-    return IBL_OK;
+    return launch_knn(ctx, g, pts, seg_off, q1, q0, q1, radius, max_nn, GradFactory{normals, grad}, status, s);
 }
 
 int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,

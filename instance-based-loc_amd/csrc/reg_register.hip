@@ -26,7 +26,7 @@
 
 // normals (radius 2 voxel, 30 nn) and FPFH (5 voxel, 100 nn) of every cloud of a batch, colour gradients (grad_radius, 30 nn) of
 // the points [gq0, gq1) -- reg_api.hip
-int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, double voxel_size,
+int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_dev, const int* seg_off_host, int n_seg, const float* bbox_host, double voxel_size,
                           double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, unsigned short* fpfh_split, float* fpfh_norm,
                           float4* grad, hipStream_t s);
 
@@ -1275,8 +1275,33 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                     hipLaunchKernelGGL(ibl_group_gather_kernel, dim3((Nd + 255) / 256), dim3(256), 0, s, d_groups, G, det, det_off_dev, mem,
                                        mem_off_dev, d_grp_off, Pd);
                     IBL_LAUNCH_CHECK();
-                    st = ibl_features_on_batch(ctx, Pd, d_grp_off, grp_off.data(), G, voxel_size, grad_radius, grp_off[G0], Nd, normals_d, fpfh_d,
-                                               split_d, norm_d, grad_d, s);
+                    // a group's bounding box is the union of its instances' boxes (the gathered points are theirs, untouched), which
+                    // the host holds with the instance features: the group grids are dimensioned without a read-back
+                    std::vector<float> grp_bbox;
+                    bool have_boxes = true;
+                    for (int g = 0; g < G && have_boxes; ++g) have_boxes = feat[groups[g].pool] != nullptr;
+                    if (have_boxes) {
+                        grp_bbox.resize((size_t)G * 6);
+                        for (int g = 0; g < G; ++g) {
+                            float* o = &grp_bbox[6 * (size_t)g];
+                            bool any = false;
+                            for (int t = 0; t < 3; ++t) {
+                                const int sg = groups[g].seg[t];
+                                if (sg < 0) continue;
+                                const int* off = groups[g].pool ? mem_off_host : det_off_host;
+                                if (off[sg + 1] == off[sg]) continue;                    // empty instance: its stored box is zeros
+                                const float* b = feat[groups[g].pool]->bbox + 6 * (size_t)sg;
+                                for (int c = 0; c < 3; ++c) {
+                                    o[c] = any ? std::min(o[c], b[c]) : b[c];
+                                    o[3 + c] = any ? std::max(o[3 + c], b[3 + c]) : b[3 + c];
+                                }
+                                any = true;
+                            }
+                            if (!any) for (int c = 0; c < 6; ++c) o[c] = 0.0f;
+                        }
+                    }
+                    st = ibl_features_on_batch(ctx, Pd, d_grp_off, grp_off.data(), G, have_boxes ? grp_bbox.data() : nullptr, voxel_size, grad_radius,
+                                               grp_off[G0], Nd, normals_d, fpfh_d, split_d, norm_d, grad_d, s);
                     if (st) return st;
                     src.normals[2] = normals_d; src.fpfh[2] = fpfh_d; src.grad[2] = grad_d; src.split[2] = split_d; src.norm[2] = norm_d;
                 }

@@ -47,20 +47,29 @@ def hf_dinov2_to_weights(sd: dict, depth: int) -> dict:
 
 
 def hf_vit_to_weights(sd: dict, depth: int) -> dict:
-    """transformers ViTModel.state_dict() (4.44 naming) -> weight dict."""
+    """transformers ViTModel.state_dict() -> weight dict.  Both parameter namings are read: transformers 4.44 (the version the reference
+    pins, environment.yml:275: `encoder.layer.N.attention.attention.query`, `intermediate.dense`, `output.dense`) and 5.x
+    (`layers.N.attention.q_proj`, `mlp.fc1`, `mlp.fc2`)."""
     g = lambda k: np.asarray(sd[k].float().cpu() if hasattr(sd[k], "float") else sd[k], dtype=np.float32)
     w = {"patch.w": g("embeddings.patch_embeddings.projection.weight"), "patch.b": g("embeddings.patch_embeddings.projection.bias"),
          "cls": g("embeddings.cls_token").reshape(-1), "pos": g("embeddings.position_embeddings")[0],
          "ln_f.g": g("layernorm.weight"), "ln_f.b": g("layernorm.bias")}
+    new_names = "layers.0.attention.q_proj.weight" in sd
     for l in range(depth):
-        p, q = f"encoder.layer.{l}.", f"l{l}."
+        p, q = (f"layers.{l}." if new_names else f"encoder.layer.{l}."), f"l{l}."
         w[q + "ln1.g"], w[q + "ln1.b"] = g(p + "layernorm_before.weight"), g(p + "layernorm_before.bias")
         w[q + "ln2.g"], w[q + "ln2.b"] = g(p + "layernorm_after.weight"), g(p + "layernorm_after.bias")
-        for hf, mine in (("query", "q"), ("key", "k"), ("value", "v")):
-            w[q + mine + ".w"], w[q + mine + ".b"] = g(p + f"attention.attention.{hf}.weight"), g(p + f"attention.attention.{hf}.bias")
-        w[q + "o.w"], w[q + "o.b"] = g(p + "attention.output.dense.weight"), g(p + "attention.output.dense.bias")
-        w[q + "fc1.w"], w[q + "fc1.b"] = g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias")
-        w[q + "fc2.w"], w[q + "fc2.b"] = g(p + "output.dense.weight"), g(p + "output.dense.bias")
+        if new_names:
+            for hf, mine in (("q_proj", "q"), ("k_proj", "k"), ("v_proj", "v"), ("o_proj", "o")):
+                w[q + mine + ".w"], w[q + mine + ".b"] = g(p + f"attention.{hf}.weight"), g(p + f"attention.{hf}.bias")
+            w[q + "fc1.w"], w[q + "fc1.b"] = g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias")
+            w[q + "fc2.w"], w[q + "fc2.b"] = g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias")
+        else:
+            for hf, mine in (("query", "q"), ("key", "k"), ("value", "v")):
+                w[q + mine + ".w"], w[q + mine + ".b"] = g(p + f"attention.attention.{hf}.weight"), g(p + f"attention.attention.{hf}.bias")
+            w[q + "o.w"], w[q + "o.b"] = g(p + "attention.output.dense.weight"), g(p + "attention.output.dense.bias")
+            w[q + "fc1.w"], w[q + "fc1.b"] = g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias")
+            w[q + "fc2.w"], w[q + "fc2.b"] = g(p + "output.dense.weight"), g(p + "output.dense.bias")
     return w
 
 
@@ -84,9 +93,10 @@ def open_clip_visual_to_weights(sd: dict, depth: int) -> dict:
     return w
 
 
-def load_encoder(kind: str, state_dict: dict, device="cuda") -> V.VitEncoder:
-    """Build + register the encoder of `kind` ("dino" | "vit" | "clip") from a checkpoint state dict."""
-    cfg = V.CONFIGS[_KIND_TO_CONFIG[kind]]
+def load_encoder(kind: str, state_dict: dict, device="cuda", cfg: V.VitConfig = None) -> V.VitEncoder:
+    """Build + register the encoder of `kind` ("dino" | "vit" | "clip") from a checkpoint state dict.  cfg: another architecture /
+    position-embedding rule than the checkpoint the reference loads (default: V.CONFIGS of the kind)."""
+    cfg = cfg or V.CONFIGS[_KIND_TO_CONFIG[kind]]
     conv = {"dino": hf_dinov2_to_weights, "vit": hf_vit_to_weights, "clip": open_clip_visual_to_weights}[kind]
     enc = V.VitEncoder(cfg, conv(state_dict, cfg.depth), device=device)
     set_encoder(kind, enc)

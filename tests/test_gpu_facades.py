@@ -67,6 +67,35 @@ def test_embeddings_facade():
         emb.get_dator_embeddings(current_obj_grounded_img=crop, current_obj_bounding_box=[0, 0, 4, 4], full_depth_image=np.ones((8, 8), np.float32))
 
 
+def test_load_encoder_from_a_transformers_checkpoint():
+    """utils.embeddings.load_encoder replaces `Dinov2Model.from_pretrained(...)` (utils/embeddings.py:18-23): a transformers
+    Dinov2Model of the facebook/dinov2-base architecture (seeded random weights; no checkpoint offline) -> state_dict -> HIP encoder ->
+    get_all_dino_embeddings must return the model's own CLS embedding of the preprocessed crop"""
+    import dataclasses
+    from transformers import Dinov2Config, Dinov2Model
+    from ibloc_amd import vit as V
+    from ibloc_amd import preprocess as pp
+    from ibloc_amd.utils import embeddings as emb
+    cfg = dataclasses.replace(V.CONFIGS["dinov2_vitb14"], pos_interp="size")       # the installed transformers (5.x) resamples with size=
+    torch.manual_seed(11)
+    m = Dinov2Model(Dinov2Config(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, mlp_ratio=4, image_size=518, patch_size=14,
+                                 qkv_bias=True, layerscale_value=1.0, use_swiglu_ffn=False, layer_norm_eps=1e-6, hidden_act="gelu")).eval()
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.add_(torch.randn(prm.shape, generator=g) * 0.02)
+    emb.load_encoder("dino", m.state_dict(), cfg=cfg)
+    crops = [np.random.default_rng(13 + i).integers(0, 256, size=s, dtype=np.uint8) for i, s in enumerate([(180, 140, 3), (224, 224, 3)])]
+    px = np.stack([vo.preprocess_crop(c, pp.RECIPES["dinov2"]) for c in crops])
+    with torch.no_grad():
+        want = m(pixel_values=torch.from_numpy(px)).last_hidden_state[:, 0].numpy()
+    got = np.stack([emb.get_all_dino_embeddings(current_obj_grounded_img=c).cpu().numpy() for c in crops])
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print("load_encoder(dino) vs transformers Dinov2Model: rel-L2", rel)
+    assert rel < 3e-3
+    emb._ENCODERS.pop("dino", None)
+
+
 def test_object_memory_localise_with_stub_finder(tmp_path):
     from ibloc_amd.object_memory.object_memory import ObjectMemory
     w = SynthWorld(4, pts_per_object=2500, E=2, D=32, seed=51)
