@@ -165,24 +165,29 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
 // ------------------------------------------------------------------------------------------------
 // registration features of a batch of clouds (shared by the instance cache and by ibl_register_batch_cached)
 // ------------------------------------------------------------------------------------------------
-// every FPFH row once more as bf16 hi | lo parts padded to 48 terms, and its squared norm (operands of reg_featnn.hip)
-__global__ __launch_bounds__(256) void ibl_fpfh_split_kernel(const float* __restrict__ fpfh, int n, unsigned short* __restrict__ split,
-                                                             float* __restrict__ norm) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)n * 48) return;
-    const int i = (int)(t / 48), k = (int)(t - (int64_t)i * 48);
-    const float v = k < 33 ? fpfh[(int64_t)i * 33 + k] : 0.0f;
-    const __bf16 bh = (__bf16)v;
-    const __bf16 bl = (__bf16)(v - (float)bh);
-    unsigned short h, l;
-    __builtin_memcpy(&h, &bh, 2);
-    __builtin_memcpy(&l, &bl, 2);
-    split[(int64_t)i * 96 + k] = h;
-    split[(int64_t)i * 96 + 48 + k] = l;
-    if (k == 47) {
-        float a = 0.0f;
-        for (int j = 0; j < 33; ++j) { const float x = fpfh[(int64_t)i * 33 + j]; a = __builtin_fmaf(x, x, a); }
-        norm[i] = a;
+// every FPFH row once more as the 48 fp16 search operands of reg_featnn.hip (layout and error budget in its header), and its
+// squared norm
+__global__ __launch_bounds__(256) void ibl_fpfh_half_kernel(const float* __restrict__ fpfh, int n, unsigned short* __restrict__ split,
+                                                            float* __restrict__ norm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* __restrict__ x = fpfh + (int64_t)i * 33;
+    _Float16 row[48];
+    float a = 0.0f;
+    for (int k = 0; k < 33; ++k) { const float v = x[k]; row[k] = (_Float16)v; a = __builtin_fmaf(v, v, a); }
+    norm[i] = a;
+    const float w = a * 0.125f;                                   // |x|^2 / 8 as fp16 hi + lo against the constant 8 of the other side
+    const _Float16 nh = (_Float16)w, nl = (_Float16)(w - (float)nh);
+    _Float16 cu = (_Float16)(1.0e-3f * a);                        // C |x|^2, rounded UP (the bound must not shrink)
+    if ((float)cu < 1.0e-3f * a) cu = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, cu) + 1));
+    row[33] = (_Float16)8.0f; row[34] = (_Float16)8.0f; row[35] = nh; row[36] = nl; row[37] = cu;
+    for (int k = 38; k < 48; ++k) row[k] = (_Float16)0.0f;
+    uint4* dst = reinterpret_cast<uint4*>(split + (int64_t)i * 48);
+#pragma unroll
+    for (int pc = 0; pc < 6; ++pc) {
+        uint4 v;
+        __builtin_memcpy(&v, &row[8 * pc], 16);
+        dst[pc] = v;
     }
 }
 
@@ -223,7 +228,7 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
         st = ibl_launch_fpfh(ctx, gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
         if (st) return st;
         if (fpfh_split && fpfh_norm) {
-            hipLaunchKernelGGL(ibl_fpfh_split_kernel, dim3((unsigned)(((int64_t)n * 48 + 255) / 256)), dim3(256), 0, s, fpfh, n, fpfh_split, fpfh_norm);
+            hipLaunchKernelGGL(ibl_fpfh_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fpfh, n, fpfh_split, fpfh_norm);
             IBL_LAUNCH_CHECK();
         }
     }
@@ -278,7 +283,7 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
         }
         const int cnt = off_host[ns];
         st = ibl_features_on_batch(ctx, P + o0, off_dev, off_host, ns, bbox_host + 6 * (size_t)s0, voxel_size, grad_radius, 0, grad4 ? cnt : 0,
-                                   reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33, fpfh_split + (int64_t)o0 * 96,
+                                   reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33, fpfh_split + (int64_t)o0 * 48,
                                    fpfh_norm + o0, grad4 ? reinterpret_cast<float4*>(grad4) + o0 : nullptr, s);
         if (st) return st;
         s0 = s1;

@@ -88,10 +88,16 @@ static inline T* arena_alloc(ibl_reg_ctx* ctx, int64_t count, bool* ok) {
 // status bits written by kernels
 #define IBL_ST_GRID_OVERFLOW 1
 #define IBL_ST_KNN_SLOWPATH 2
+#define IBL_ST_FEAT_OVERFLOW 4       // the matrix-core feature search overflowed its candidate list: the call is redone with the VALU search
+#define IBL_ST_RANSAC_OVERFLOW 8     // more surviving hypotheses in a round than the list holds (ibl_register_batch returns an error)
 
 // grid construction (reg_grid.hip)
 int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
                          float cell, int64_t max_cells, BatchGrid* out, hipStream_t s);
+// The same grid without the read-back of the table size: `cells_bound` (>= the number of cells the dims kernel will find, e.g. from
+// bounding boxes the host already holds) sizes the tables; a segment that does not fit collapses to one cell (status bit).
+int ibl_build_batch_grid_bounded(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
+                                 float cell, int64_t cells_bound, BatchGrid* out, hipStream_t s);
 // Grid for the hybrid k-NN kernels, sized on the HOST from the segments' bounding boxes (bbox_host [S][6], the values
 // ibl_launch_bbox produced): no read-back, no dims kernel.  The cell of a segment follows its point density (about max_nn points
 // inside a ball of two cells, clamped to [radius / 12, radius]), tiles are cubes of ts^3 cells.

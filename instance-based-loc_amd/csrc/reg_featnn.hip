@@ -1,24 +1,29 @@
 // reg_featnn.hip -- 33-d nearest-neighbour search of the registration features on the matrix cores.
 //
 // The search (utils/fpfh_register.py:110-119 -> Open3D's feature matching: for every point the nearest feature of the other
-// cloud) is a dense distance matrix.  On the synthetic workload the detections keep ~800 noisy points after outlier
-// removal, their nearest features are far (d2 ~ 1000) and the early-abandon VALU search of reg_register.hip runs nearly the
-// whole 33-term chain for every candidate: 80 VALU instructions per (wave, candidate), 8.6 ms per step.  Here the matrix
-// cores do the bulk and the exact arithmetic is kept for the few candidates that can matter:
-//   d2(q, t) = |q|^2 + |t|^2 - 2 q.t,   q.t ~ qh.th + qh.tl + ql.th   (x = xh + xl + r, bf16 hi/lo split, |r| <= 2^-16 |x|)
-// computed with v_mfma_f32_32x32x16_bf16 (three products x three 16-wide k steps over the 33 -> 48 padded terms).  Error of
-// approx against the fp32 chain the VALU search / oracle evaluates, with N = |q|^2 + |t|^2 (so |q||t| <= N / 2, d2 <= 2 N):
-//   split      bf16 keeps 8 significant bits: |x - xh| <= 2^-8 |x|, |x - xh - xl| <= 2^-16 |x|; the dropped terms ql.tl, rq.t,
-//              q.rt are each <= 2^-16 |q||t|, times the factor 2 of the expansion:          6 * 2^-16 |q||t| <= 4.6e-5 N
-//   accumulate 144 exact bf16 products summed in fp32 by the MFMAs, times 2:                 1.8e-5 |q||t|    <= 0.9e-5 N
-//   norms      two 33-term fp32 fmaf chains:                                                                     0.2e-5 N
-//   chain      the exact chain's own rounding (34 roundings of values <= d2):                                    0.4e-5 N
-//   epilogue   the three fp32 operations that form the bound:                                                    0.1e-5 N
-// total <= 6.2e-5 N; E = FM_C N with FM_C = 7e-5.
-//   pass 1   up(q) = min_t (approx + E)                       -- an upper bound of the exact minimum
-//   pass 2   every t with approx - E <= up(q) is a candidate  -- the exact minimiser (and every exact tie) is among them
+// cloud) is a dense distance matrix: 5 000 x 5 000 rows per instance pair, ~600 pairs and both directions per bench step.  The
+// matrix cores do the bulk and the exact arithmetic is kept for the few candidates that can matter.  Every feature row is stored
+// once more as 48 fp16 "search operands" (ibl_fpfh_half_kernel):
+//   x'  = [ x_0 .. x_32 | 8  8 | nh  nl | cu | 0 ... ]      nh + nl = |x|^2 / 8 (fp16 hi + lo),  cu = C |x|^2 rounded up
+// and a query row is turned in registers into
+//   q'' = [ -2 q_0 .. -2 q_32 | sh  sl | 8  8 | +-1 | 0 ... ]   sh + sl = (1 +- C) |q|^2 / 8
+// so that ONE MFMA chain (three v_mfma_f32_32x32x16_f16 over the 48 terms) yields the whole bound
+//   q'' . t' = (1 +- C)|q|^2 + |t|^2 +- C|t|^2 - 2 qh.th  =  d2_approx +- E,      E = C (|q|^2 + |t|^2)
+// and the epilogue is a minimum (pass 1) or a compare (pass 2) per distance -- no norm adds, no hi/lo split products (the bf16
+// hi | lo operands of round 1 needed three products per distance: 3x the matrix work, 2x the operand bytes).
+// Error of d2_approx against the fp32 chain the VALU search / oracle evaluates, with N = |q|^2 + |t|^2 (|q||t| <= N / 2):
+//   operands   fp16 keeps 11 significant bits, |x - xh| <= 2^-11 |x| (feature values are 0 .. 200: no overflow, no subnormals that
+//              matter): |q.t - qh.th| <= 2^-11 (2 + 2^-11) |q||t|, times the factor 2 of the expansion:       <= 9.78e-4 N
+//   accumulate 38 exact fp16 products summed in fp32 by the MFMAs (largest partial sum ~N):                    <= 0.5e-5 N
+//   norms      fp32 fmaf chains, stored as fp16 hi + lo pairs (2^-22 relative):                                <= 0.3e-5 N
+//   chain      the exact chain's own rounding (34 roundings of values <= d2 <= 2 N):                           <= 0.4e-5 N
+// total <= 9.9e-4 N; E = FM_C N with FM_C = 1.0e-3 (the C|t|^2 slot is rounded UP to fp16, the query's factor is applied in fp32).
+//   pass 1   up(q) = min_t (d2_approx + E)                    -- an upper bound of the exact minimum
+//   pass 2   every t with d2_approx - E <= up(q) is a candidate -- the exact minimiser (and every exact tie) is among them
 //   exact    the fp32 fmaf chain of the VALU search for each candidate, folded with a 64-bit atomic min on
 //            (distance bits, database index): the lexicographic minimum, i.e. exactly the result of the full scan.
+// The band 2 E is ~14x wider than with the split operands, so pass 2 passes ~4 instead of ~2 candidates per query to the exact
+// kernel -- 0.5 ms more there against 6 ms less here.
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
@@ -27,26 +32,32 @@
 
 #include "reg_common.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 fm_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 fm_h16x8;
 typedef __attribute__((ext_vector_type(16))) float fm_f32x16;
 
 #define FM_DT 32                 // database rows per chunk (one 32 x 32 MFMA tile per wave)
-#define FM_ROWB 112              // LDS bytes per row: 48 bf16 + 16 pad (2-way instead of 4-way bank conflicts on ds_read_b128)
-#define FM_C 7e-5f               // E = FM_C (|q|^2 + |t|^2)
+#define FM_ROWB 112              // LDS bytes per row: 48 fp16 + 16 pad (2-way instead of 4-way bank conflicts on ds_read_b128)
+#define FM_C 1.0e-3f             // E = FM_C (|q|^2 + |t|^2)
+#define FM_NS 8.0f               // norms are stored divided by 8 (|x|^2 reaches 1.2e5, fp16 ends at 65 504) against a constant 8
 #define FM_NQ 2                  // 32-query tiles per wave (they share every database fragment read)
 #define FM_QUEUE 256             // per-wave candidate queue, flushed when fewer than 64 slots (one append step) are left
 
 struct FmCand { int pair, qi, t, pad; };
 
 struct FmTile {
-    __attribute__((aligned(16))) unsigned char hi[FM_DT * FM_ROWB];
-    __attribute__((aligned(16))) unsigned char lo[FM_DT * FM_ROWB];
-    __attribute__((aligned(16))) float dn[FM_DT];        // (1 +- C) |t|^2 for pass 1 / 2   (+inf past the end of the database)
+    __attribute__((aligned(16))) unsigned char rows[FM_DT * FM_ROWB];      // search operands of 32 database rows
 };
 
-// grid (query tiles of 128 FM_NQ, pairs); PASS 1: up[] ; PASS 2: candidates.  Operands come pre-split from the instance features
-// (fpfh_split: 48 hi | 48 lo bf16 per row, fpfh_norm).  Database chunks of 32 rows are copied to LDS (16-byte pieces, fetched
-// into registers one chunk ahead); every wave holds its 32 queries as the B operand in registers.
+// fp32 value -> fp16 hi + lo of value / FM_NS
+__device__ __forceinline__ void fm_split_norm(float v, _Float16* h, _Float16* l) {
+    const float w = v * (1.0f / FM_NS);
+    *h = (_Float16)w;
+    *l = (_Float16)(w - (float)*h);
+}
+
+// grid (query tiles of 128 FM_NQ, pairs); PASS 1: up[] ; PASS 2: candidates.  Operands come from the instance features
+// (fpfh_split: 48 fp16 per row, laid out as in the file header).  Database chunks of 32 rows are copied to LDS (16-byte pieces,
+// fetched into registers one chunk ahead); every wave holds its 32 queries as the B operand in registers.
 template <int PASS, bool INDEXED>
 __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __restrict__ pairs, FeatSources src, float* __restrict__ up,
                                                             FmCand* __restrict__ cand, int* __restrict__ n_cand, int cand_cap,
@@ -59,17 +70,16 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
     __shared__ FmTile tiles[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kg = lane >> 5;
-    const uint4* __restrict__ qs = reinterpret_cast<const uint4*>(src.split[P.qkind] + (int64_t)P.qsrc * 96);
-    const uint4* __restrict__ ds = reinterpret_cast<const uint4*>(src.split[P.dkind] + (int64_t)P.dsrc * 96);     // 12 pieces per row
-    const float* __restrict__ dnorm = src.norm[P.dkind] + P.dsrc;
+    const uint4* __restrict__ qs = reinterpret_cast<const uint4*>(src.split[P.qkind] + (int64_t)P.qsrc * 48);      // 6 pieces per row
+    const uint4* __restrict__ ds = reinterpret_cast<const uint4*>(src.split[P.dkind] + (int64_t)P.dsrc * 48);
     constexpr float SGN = PASS == 1 ? 1.0f + FM_C : 1.0f - FM_C;
 
     // this wave's FM_NQ x 32 queries as B operands (one set of database fragments serves them all): lane (n, kg) holds terms
-    // 16 s + 8 kg + 0..7 of query n for k step s
+    // 16 s + 8 kg + 0..7 of query n for k step s, turned from the stored x' into q'' (file header)
     bool valid[FM_NQ];
     int qi[FM_NQ];                                     // local index inside the query instance
-    fm_bf16x8 qh[FM_NQ][3], ql[FM_NQ][3];
-    float qn_s[FM_NQ], mup[FM_NQ];
+    fm_h16x8 qh[FM_NQ][3];
+    float mup[FM_NQ];
 #pragma unroll
     for (int u = 0; u < FM_NQ; ++u) {
         const int qv = q0 + (wave * FM_NQ + u) * 32 + n;
@@ -78,35 +88,36 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
         qi[u] = INDEXED ? need_list[l0 + qc] - (P.out - out0) : qc;
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
-            const uint4 h = qs[(int64_t)qi[u] * 12 + 2 * s3 + kg], l = qs[(int64_t)qi[u] * 12 + 6 + 2 * s3 + kg];
+            const uint4 h = qs[(int64_t)qi[u] * 6 + 2 * s3 + kg];
             __builtin_memcpy(&qh[u][s3], &h, 16);
-            __builtin_memcpy(&ql[u][s3], &l, 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qh[u][s3][e] = (_Float16)-2.0f * qh[u][s3][e];      // exact (a power of two)
         }
-        qn_s[u] = src.norm[P.qkind][P.qsrc + qi[u]] * SGN;
+        if (kg == 0) {                                  // terms 32 .. 39 live on the kg = 0 lanes of k step 2
+            _Float16 sh, sl;
+            fm_split_norm(src.norm[P.qkind][P.qsrc + qi[u]] * SGN, &sh, &sl);
+            qh[u][2][1] = sh; qh[u][2][2] = sl;
+            qh[u][2][3] = (_Float16)FM_NS; qh[u][2][4] = (_Float16)FM_NS;
+            qh[u][2][5] = (_Float16)(PASS == 1 ? 1.0f : -1.0f);
+            qh[u][2][6] = (_Float16)0.0f; qh[u][2][7] = (_Float16)0.0f;
+        }
         mup[u] = PASS == 1 ? INFINITY : up[P.out + qi[u]];
     }
 
-    // chunk staging: 32 rows x 12 pieces = 384 pieces of 16 bytes; thread t carries pieces t and t + 256 (t < 128)
+    // chunk staging: 32 rows x 6 pieces = 192 pieces of 16 bytes, one per thread (threads 192 .. 255 idle here).  Rows past the
+    // end of the database get a squared norm beyond any real bound instead (terms 35 / 36; d2 <= 2 N <= 4.8e5 for FPFH rows, whose
+    // histograms sum to 200), so that they are never the minimum of pass 1; pass 2 checks the row index
     const int n_chunks = (P.dcnt + FM_DT - 1) / FM_DT;
-    uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
-    float pren = INFINITY;
+    uint4 pre0 = make_uint4(0, 0, 0, 0);
+    const int r0 = tid / 6, p0 = tid - r0 * 6;
     auto fetch = [&](int t0) {
-        const int r0 = tid / 12, p0 = tid - r0 * 12;
-        pre0 = t0 + r0 < P.dcnt ? ds[(int64_t)(t0 + r0) * 12 + p0] : make_uint4(0, 0, 0, 0);
-        if (tid < 128) {
-            const int e = tid + 256, r1 = e / 12, p1 = e - r1 * 12;
-            pre1 = t0 + r1 < P.dcnt ? ds[(int64_t)(t0 + r1) * 12 + p1] : make_uint4(0, 0, 0, 0);
+        if (tid < 192) {
+            if (t0 + r0 < P.dcnt) pre0 = ds[(int64_t)(t0 + r0) * 6 + p0];
+            else pre0 = p0 == 4 ? make_uint4(0, 0x7BFFu << 16, 0x7BFFu, 0) : make_uint4(0, 0, 0, 0);      // terms 35, 36 = 65 504: a bound of 1.05e6 > 2 N
         }
-        if (tid < FM_DT) pren = t0 + tid < P.dcnt ? dnorm[t0 + tid] * SGN : INFINITY;
     };
     auto stash = [&](FmTile& T) {
-        const int r0 = tid / 12, p0 = tid - r0 * 12;
-        *reinterpret_cast<uint4*>((p0 < 6 ? T.hi : T.lo) + r0 * FM_ROWB + 16 * (p0 < 6 ? p0 : p0 - 6)) = pre0;
-        if (tid < 128) {
-            const int e = tid + 256, r1 = e / 12, p1 = e - r1 * 12;
-            *reinterpret_cast<uint4*>((p1 < 6 ? T.hi : T.lo) + r1 * FM_ROWB + 16 * (p1 < 6 ? p1 : p1 - 6)) = pre1;
-        }
-        if (tid < FM_DT) T.dn[tid] = pren;
+        if (tid < 192) *reinterpret_cast<uint4*>(T.rows + r0 * FM_ROWB + 16 * p0) = pre0;
     };
     __shared__ int2 queue[PASS == 2 ? 4 : 1][PASS == 2 ? FM_QUEUE : 1];
     int qcount = 0;                                  // wave-uniform
@@ -137,28 +148,17 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
             // A operand: lane (m = n, kg) holds terms 16 s + 8 kg + 0..7 of database row m
-            const fm_bf16x8 ah = *reinterpret_cast<const fm_bf16x8*>(T.hi + n * FM_ROWB + 32 * s3 + 16 * kg);
-            const fm_bf16x8 al = *reinterpret_cast<const fm_bf16x8*>(T.lo + n * FM_ROWB + 32 * s3 + 16 * kg);
+            const fm_h16x8 ah = *reinterpret_cast<const fm_h16x8*>(T.rows + n * FM_ROWB + 32 * s3 + 16 * kg);
 #pragma unroll
-            for (int u = 0; u < FM_NQ; ++u) {
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[u][s3], acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[u][s3], acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[u][s3], acc[u], 0, 0, 0);
-            }
+            for (int u = 0; u < FM_NQ; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[u][s3], acc[u], 0, 0, 0);
         }
-        // acc[u][i] = q . t for database row m = 8 (i / 4) + 4 kg + (i % 4) of the chunk and query n of tile u;
-        // bound(i) = (1 +- C)(|q|^2 + |t|^2) - 2 q . t
-        float dnv[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 du = *reinterpret_cast<const float4*>(&T.dn[8 * g + 4 * kg]);
-            dnv[4 * g] = du.x; dnv[4 * g + 1] = du.y; dnv[4 * g + 2] = du.z; dnv[4 * g + 3] = du.w;
-        }
+        // acc[u][i] = the bound (d2_approx + E in pass 1, - E in pass 2) of database row m = 8 (i / 4) + 4 kg + (i % 4) of the chunk
+        // and query n of tile u
 #pragma unroll
         for (int u = 0; u < FM_NQ; ++u) {
             float lowest = INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lowest = fminf(lowest, __builtin_fmaf(-2.0f, acc[u][i], dnv[i] + qn_s[u]));
+            for (int i = 0; i < 16; ++i) lowest = fminf(lowest, acc[u][i]);
             if (PASS == 1) {
                 mup[u] = fminf(mup[u], lowest);
             } else if (__ballot(lowest <= mup[u] && valid[u]) != 0ull) {
@@ -167,10 +167,11 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
                 // (two million same-address atomics per step took longer than the whole search)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const bool hit = valid[u] && __builtin_fmaf(-2.0f, acc[u][i], dnv[i] + qn_s[u]) <= mup[u];
+                    const int row = c * FM_DT + 8 * (i >> 2) + 4 * kg + (i & 3);
+                    const bool hit = valid[u] && acc[u][i] <= mup[u] && row < P.dcnt;
                     const unsigned long long m = __ballot(hit);
                     if (m) {
-                        if (hit) queue[wave][qcount + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(qi[u], c * FM_DT + 8 * (i >> 2) + 4 * kg + (i & 3));
+                        if (hit) queue[wave][qcount + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(qi[u], row);
                         qcount += __popcll(m);
                         if (qcount > FM_QUEUE - 64) flush();
                     }
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(256) void ibl_feat_exact_kernel(const FeatPair* __r
 }
 
 __global__ __launch_bounds__(256) void ibl_feat_finish_kernel(const unsigned long long* __restrict__ best, int64_t i0, int64_t n,
-                                                              int* __restrict__ pair_idx, float* __restrict__ pair_d2) {
+                                                              int* __restrict__ pair_idx, float* __restrict__ pair_d2,
+                                                              const int* __restrict__ n_cand, int cand_cap, int* __restrict__ status) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *n_cand > cand_cap) atomicOr(status, IBL_ST_FEAT_OVERFLOW);
     const int64_t i = i0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= i0 + n) return;
     const unsigned long long k = best[i];
@@ -254,12 +257,10 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
     }
     hipLaunchKernelGGL(ibl_feat_exact_kernel, dim3(2048), dim3(256), 0, s, d_pairs, src, cand, n_cand, cand_cap, best0);
     IBL_LAUNCH_CHECK();
+    // a candidate list that overflowed sets IBL_ST_FEAT_OVERFLOW in the context's status word; the driver reads it with its results
+    // and redoes the call with the VALU search (no read-back here)
     hipLaunchKernelGGL(ibl_feat_finish_kernel, dim3((unsigned)((out_count + 255) / 256)), dim3(256), 0, s, best0, (int64_t)out0, out_count,
-                       pair_idx, pair_d2);
+                       pair_idx, pair_d2, n_cand, cand_cap, ctx->d_status);
     IBL_LAUNCH_CHECK();
-    int h_cand = 0;
-    IBL_HIP_CHECK(hipMemcpyAsync(&h_cand, n_cand, sizeof(int), hipMemcpyDeviceToHost, s));
-    IBL_HIP_CHECK(hipStreamSynchronize(s));
-    if (h_cand > cand_cap) *overflow = true;
     return IBL_OK;
 }

@@ -206,6 +206,24 @@ int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off
     return grid_fill(ctx, pts, seg_off_dev, n_seg, n, seg, h_total, out, s);
 }
 
+int ibl_build_batch_grid_bounded(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
+                                 float cell, int64_t cells_bound, BatchGrid* out, hipStream_t s) {
+    const int n = seg_off_host[n_seg];
+    float* bbox; SegGrid* seg; int* total;
+    IBL_ARENA(bbox, float, (int64_t)n_seg * 6 + 6);
+    IBL_ARENA(seg, SegGrid, n_seg + 1);
+    IBL_ARENA(total, int, 4);
+    out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
+    out->tile_base = nullptr; out->n_tiles = 0; out->ts = 0;
+    if (n_seg == 0) return IBL_OK;
+    if (cells_bound <= 0 || cells_bound > 0x7fff0000ll) return ibl_set_error(IBL_ERR_OVERFLOW, "grid: cell bound %lld out of range", (long long)cells_bound);
+    hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox);
+    IBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ibl_grid_dims_kernel, dim3(1), dim3(256), 0, s, bbox, n_seg, cell, (long long)cells_bound, seg, total, ctx->d_status);
+    IBL_LAUNCH_CHECK();
+    return grid_fill(ctx, pts, seg_off_dev, n_seg, n, seg, (int)cells_bound, out, s);
+}
+
 double ibl_knn_safety() {
     static const double v = [] { const char* e = getenv("IBL_KNN_SAFETY"); return e ? atof(e) : 1.0; }();
     return v;

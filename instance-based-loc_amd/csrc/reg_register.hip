@@ -30,6 +30,9 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
                           double grad_radius, int gq0, int gq1, float4* normals, float* fpfh, unsigned short* fpfh_split, float* fpfh_norm,
                           float4* grad, hipStream_t s);
 
+#ifndef ICP_CELL_DIV
+#define ICP_CELL_DIV 2.0     // cells of the ICP neighbour grid per correspondence distance (finer cells: fewer candidates per walk)
+#endif
 #define ICP_BPJ 8        // blocks per job in the ICP / evaluation reductions (each ends in a 29-value fp64 block reduction)
 #define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
 
@@ -404,7 +407,7 @@ struct RansacState {
 };
 
 __global__ void ibl_ransac_init_kernel(RansacState* __restrict__ st, const int* __restrict__ n_corr, int J, long long max_iter,
-                                       double max_dist, int* __restrict__ active, int* __restrict__ n_active) {
+                                       double max_dist, int* __restrict__ active) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= J) return;
     RansacState s;
@@ -412,7 +415,13 @@ __global__ void ibl_ransac_init_kernel(RansacState* __restrict__ st, const int* 
     s.best_fit = 0; s.best_rmse = 0; s.est_k = max_iter; s.next_i = 0; s.walked = 0; s.validated = 0; s.best_inl = 0; s.last_update = -1;
     s.done = (n_corr[j] < 3 || max_dist <= 0) ? 1 : 0;
     st[j] = s;
-    if (!s.done) active[atomicAdd(n_active, 1)] = j;
+    active[j] = j;           // the first rounds run every job slot (a finished job's blocks leave at once); the host compacts later
+}
+
+// done flags for the host's read-back between groups of rounds
+__global__ void ibl_ransac_done_kernel(const RansacState* __restrict__ st, int J, int* __restrict__ done) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < J) done[j] = st[j].done;
 }
 
 // packed correspondences: cp[2c] = source point, cp[2c + 1] = target point
@@ -542,6 +551,10 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
     // L2 latency with two waves per SIMD to hide it.  Up to RANSAC_LDS_CORR of them are staged in LDS once per block (a block draws
     // from them 6 x 4096 ... 16384 times); larger jobs keep reading global memory.  Same values either way.
     __shared__ float4 sc[2 * RANSAC_LDS_CORR];
+    if (!job_on) {            // uniform per block: nothing survives, the counts of this block's 256-hypothesis groups are zero
+        if (threadIdx.x < 4 * RANSAC_SUBS) blk_cnt[a * nblk + blockIdx.x * (4 * RANSAC_SUBS) + threadIdx.x] = 0;
+        return;
+    }
     const bool in_lds = nc <= RANSAC_LDS_CORR;
     if (in_lds && job_on)
         for (int t = threadIdx.x; t < 2 * nc; t += 256) sc[t] = c[t];
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
 }
 
 __global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned char* __restrict__ flags, const int* __restrict__ blk_off,
-                                                                 int round_size, int* __restrict__ list /* slot ids, ordered */) {
+                                                                 int round_size, int* __restrict__ list /* slot ids, ordered */, int list_cap) {
     const int a = blockIdx.y;
     const int nblk = round_size / 256;
     const int slot = blockIdx.x * 256 + threadIdx.x;
@@ -594,7 +607,8 @@ __global__ __launch_bounds__(256) void ibl_ransac_scatter_kernel(const unsigned 
     if (ok) {
         int pre = blk_off[a * nblk + blockIdx.x];
         for (int w = 0; w < wave; ++w) pre += wc[w];
-        list[pre + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+        const int pos = pre + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < list_cap) list[pos] = slot;              // an overflowing round is reported by the transform kernel
     }
 }
 
@@ -603,11 +617,16 @@ __global__ __launch_bounds__(256) void ibl_ransac_transform_kernel(const RansacS
                                                                    const int* __restrict__ job_off, const int* __restrict__ n_corr,
                                                                    const int* __restrict__ active, int n_active, double max_dist, double edge_sim,
                                                                    unsigned seed_lo, unsigned seed_hi, unsigned job_id_base, int round_size,
-                                                                   const int* __restrict__ blk_off, const int* __restrict__ list, int total,
+                                                                   const int* __restrict__ blk_off, const int* __restrict__ list,
+                                                                   const int* __restrict__ total_ptr, int list_cap, int* __restrict__ status,
                                                                    int* __restrict__ e_job, double* __restrict__ e_T) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+    int total = *total_ptr;                    // the round's survivors: the last entry of the block-count scan
+    if (total > list_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, IBL_ST_RANSAC_OVERFLOW);
+        total = list_cap;
+    }
     const int nblk = round_size / 256;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     int lo = 0, hi = n_active;                // largest active slot a with blk_off[a * nblk] <= e
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -620,16 +639,18 @@ __global__ __launch_bounds__(256) void ibl_ransac_transform_kernel(const RansacS
     e_job[e] = j;
 #pragma unroll
     for (int t = 0; t < 12; ++t) e_T[(int64_t)e * 12 + t] = T[t];
+    }
 }
 
 // wave per survivor: inliers and squared error of its transform over the job's correspondences
 __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const float4* __restrict__ cp, const int* __restrict__ job_off,
-                                                               const int* __restrict__ n_corr, double max_dist, int total,
+                                                               const int* __restrict__ n_corr, double max_dist,
+                                                               const int* __restrict__ total_ptr, int list_cap,
                                                                const int* __restrict__ e_job, const double* __restrict__ e_T,
                                                                int* __restrict__ e_inl, double* __restrict__ e_err2) {
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= total) return;
+    const int total = min(*total_ptr, list_cap);
     const int lane = threadIdx.x & 63;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += gridDim.x * 4) {
     const int j = e_job[e];
     const float4* c = cp + 2 * (int64_t)job_off[j];
     const int nc = n_corr[j];
@@ -653,6 +674,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_score_kernel(const float4* __r
     inl = wave_sum_i(inl);
     err2 = wave_sum_d(err2);
     if (lane == 0) { e_inl[e] = inl; e_err2[e] = err2; }
+    }
 }
 
 // wave per job: fold the round's survivors in hypothesis order
@@ -660,8 +682,7 @@ __global__ __launch_bounds__(64) void ibl_ransac_fold_kernel(RansacState* __rest
                                                              long long max_iter, double confidence, int round_size,
                                                              const int* __restrict__ blk_off, const int* __restrict__ list,
                                                              const int* __restrict__ e_inl, const double* __restrict__ e_err2,
-                                                             const double* __restrict__ e_T, int total, int* __restrict__ n_active,
-                                                             const int* __restrict__ active, int* __restrict__ active_next) {
+                                                             const double* __restrict__ e_T, const int* __restrict__ active) {
     const int a = blockIdx.x, j = active[a];
     const int lane = threadIdx.x;
     RansacState S = st[j];
@@ -714,10 +735,7 @@ __global__ __launch_bounds__(64) void ibl_ransac_fold_kernel(RansacState* __rest
     // best_T lanes 0..11 were written by the owning lanes: gather them to lane 0's copy
     double bt = lane < 12 ? S.best_T[lane] : 0.0;
     for (int t = 0; t < 12; ++t) { const double v = __shfl(bt, t, 64); if (lane == 0) S.best_T[t] = v; }
-    if (lane == 0) {
-        st[j] = S;
-        if (!S.done) active_next[atomicAdd(n_active, 1)] = j;     // order irrelevant: all per-round tables are indexed by job id
-    }
+    if (lane == 0) st[j] = S;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -961,6 +979,9 @@ __global__ __launch_bounds__(64) void ibl_icp_update_kernel(IcpState* __restrict
 // ------------------------------------------------------------------------------------------------
 // the fused driver
 // ------------------------------------------------------------------------------------------------
+static thread_local bool tl_force_valu = false;     // set while a call is redone after the matrix-core search overflowed its list
+
+__global__ void ibl_status_clear_kernel(int* __restrict__ status, int mask) { atomicAnd(status, ~mask); }
 extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
                                   int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
                                   int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs, double voxel_size,
@@ -990,6 +1011,8 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     const bool center = (flags & IBL_REG_CENTER) != 0;
     hipStream_t s = (hipStream_t)stream;
     ArenaMark mark(ctx);
+    hipLaunchKernelGGL(ibl_status_clear_kernel, dim3(1), dim3(1), 0, s, ctx->d_status, IBL_ST_FEAT_OVERFLOW | IBL_ST_RANSAC_OVERFLOW);
+    IBL_LAUNCH_CHECK();
     const bool timing = getenv("IBL_TIMING") != nullptr;
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t_prev = now();
@@ -1025,8 +1048,10 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     IBL_ARENA(d_means, double, (int64_t)J * 6);
     IBL_ARENA(P, float4, N + 1);
     IBL_ARENA(normals, float4, N + 1);
-    IBL_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(JobDesc) * J, hipMemcpyHostToDevice, s));
-    IBL_HIP_CHECK(hipMemcpyAsync(d_job_off, job_off.data(), sizeof(int) * (2 * J + 1), hipMemcpyHostToDevice, s));
+    int st = ibl_stage_upload(ctx, d_jobs, jobs.data(), sizeof(JobDesc) * (int64_t)J, s);
+    if (st) return st;
+    st = ibl_stage_upload(ctx, d_job_off, job_off.data(), sizeof(int) * (int64_t)(2 * J + 1), s);
+    if (st) return st;
     const float4* det = reinterpret_cast<const float4*>(det_pts4);
     const float4* mem = reinterpret_cast<const float4*>(mem_pts4);
     hipLaunchKernelGGL(ibl_job_mean_kernel, dim3(J, 2), dim3(256), 0, s, d_jobs, det, det_off_dev, mem, mem_off_dev, center ? 1 : 0, d_means);
@@ -1036,20 +1061,43 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                            d_job_off, d_means, P);
         IBL_LAUNCH_CHECK();
     }
-    // pageable host copies below are synchronous w.r.t. the stream contents issued so far
-    IBL_HIP_CHECK(hipStreamSynchronize(s));   // job_off / jobs host vectors must outlive their H2D copies
-
     RansacState* rs = nullptr;
     IcpState* is;
     IBL_ARENA(is, IcpState, J);
     const double max_dist_icp = voxel_size * local_dist_factor;
-    int st;
 
     // grid C (cell = ICP correspondence distance) lives until the end: ICP neighbours (reach 1) and colour gradients
     // (radius 2 * max_dist, reach 2); grid A (cell = normal radius) only serves the normals
     phase("job assembly");
     BatchGrid gC;
-    st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)max_dist_icp, (int64_t)128 << 20, &gC, s);
+    {
+        // With the instance boxes on the host (instance features carry them) the table is sized from an upper bound of every job
+        // side's extent -- centring moves a side, it does not stretch it beyond rounding -- and the build needs no read-back.
+        int64_t bound = 0;
+        bool have = det_features && mem_features && det_features->bbox && mem_features->bbox;
+        for (int sgi = 0; sgi < 2 * J && have; ++sgi) {
+            const int pl = sgi >= J ? 1 : 0, j = pl ? sgi - J : sgi;
+            const int* segs = pl ? jobs[j].tgt_seg : jobs[j].src_seg;
+            const int* off = pl ? mem_off_host : det_off_host;
+            const float* boxes = pl ? mem_features->bbox : det_features->bbox;
+            float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            bool any = false;
+            for (int t = 0; t < 3; ++t) {
+                if (segs[t] < 0 || off[segs[t] + 1] == off[segs[t]]) continue;
+                const float* b = boxes + 6 * (size_t)segs[t];
+                for (int c = 0; c < 3; ++c) { lo[c] = any ? std::min(lo[c], b[c]) : b[c]; hi[c] = any ? std::max(hi[c], b[3 + c]) : b[3 + c]; }
+                any = true;
+            }
+            double cells = 1;
+            float cell = (float)(max_dist_icp / ICP_CELL_DIV);
+            const float emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+            if (emax * 1.0001f / 128.0f > cell) cell = emax / 128.0f;
+            for (int c = 0; c < 3; ++c) cells *= std::floor((double)(hi[c] - lo[c]) * 1.0001 / cell) + 2.0;
+            bound += (int64_t)cells;
+        }
+        if (have && bound < ((int64_t)128 << 20)) st = ibl_build_batch_grid_bounded(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(max_dist_icp / ICP_CELL_DIV), bound, &gC, s);
+        else st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(max_dist_icp / ICP_CELL_DIV), (int64_t)128 << 20, &gC, s);
+    }
     if (st) return st;
     phase("grid C");
     float4* grad = nullptr;
@@ -1123,7 +1171,8 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 NearPair* d_near; int* d_flags;
                 IBL_ARENA(d_near, NearPair, (int64_t)near.size());
                 IBL_ARENA(d_flags, int, (int64_t)near.size());
-                IBL_HIP_CHECK(hipMemcpyAsync(d_near, near.data(), sizeof(NearPair) * near.size(), hipMemcpyHostToDevice, s));
+                st = ibl_stage_upload(ctx, d_near, near.data(), sizeof(NearPair) * (int64_t)near.size(), s);
+                if (st) return st;
                 IBL_HIP_CHECK(hipMemsetAsync(d_flags, 0, sizeof(int) * near.size(), s));
                 const float Rf = nextafterf((float)R, INFINITY);
                 for (size_t p0 = 0; p0 < near.size(); p0 += 32768) {
@@ -1268,10 +1317,12 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                     IBL_ARENA(normals_d, float4, Nd + 1);
                     IBL_ARENA(grad_d, float4, Nd + 1);
                     IBL_ARENA(fpfh_d, float, (int64_t)Nd * 33 + 64);
-                    IBL_ARENA(split_d, unsigned short, (int64_t)Nd * 96 + 64);
+                    IBL_ARENA(split_d, unsigned short, (int64_t)Nd * 48 + 64);
                     IBL_ARENA(norm_d, float, (int64_t)Nd + 64);
-                    IBL_HIP_CHECK(hipMemcpyAsync(d_groups, groups.data(), sizeof(GroupDesc) * G, hipMemcpyHostToDevice, s));
-                    IBL_HIP_CHECK(hipMemcpyAsync(d_grp_off, grp_off.data(), sizeof(int) * (G + 1), hipMemcpyHostToDevice, s));
+                    st = ibl_stage_upload(ctx, d_groups, groups.data(), sizeof(GroupDesc) * (int64_t)G, s);
+                    if (st) return st;
+                    st = ibl_stage_upload(ctx, d_grp_off, grp_off.data(), sizeof(int) * (int64_t)(G + 1), s);
+                    if (st) return st;
                     hipLaunchKernelGGL(ibl_group_gather_kernel, dim3((Nd + 255) / 256), dim3(256), 0, s, d_groups, G, det, det_off_dev, mem,
                                        mem_off_dev, d_grp_off, Pd);
                     IBL_LAUNCH_CHECK();
@@ -1308,7 +1359,8 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 if (!copies.empty()) {
                     FeatCopy* d_copies;
                     IBL_ARENA(d_copies, FeatCopy, (int64_t)copies.size());
-                    IBL_HIP_CHECK(hipMemcpyAsync(d_copies, copies.data(), sizeof(FeatCopy) * copies.size(), hipMemcpyHostToDevice, s));
+                    st = ibl_stage_upload(ctx, d_copies, copies.data(), sizeof(FeatCopy) * (int64_t)copies.size(), s);
+                    if (st) return st;
                     for (size_t c0 = 0; c0 < copies.size(); c0 += 32768) {
                         const unsigned nc = (unsigned)std::min<size_t>(32768, copies.size() - c0);
                         hipLaunchKernelGGL(ibl_feat_assemble_kernel, dim3(8, nc), dim3(256), 0, s, d_copies + c0, src, normals, (float*)nullptr, grad);
@@ -1317,12 +1369,14 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 }
                 phase("recomputed groups + assemble");
                 // matching reads the features in place (caches / recomputed groups), once per distinct pair
-                IBL_HIP_CHECK(hipMemcpyAsync(d_sides, sides.data(), sizeof(SidePairs) * sides.size(), hipMemcpyHostToDevice, s));
+                st = ibl_stage_upload(ctx, d_sides, sides.data(), sizeof(SidePairs) * (int64_t)sides.size(), s);
+                if (st) return st;
                 if (!pairs.empty() && N > 0) {
-                    IBL_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(FeatPair) * pairs.size(), hipMemcpyHostToDevice, s));
+                    st = ibl_stage_upload(ctx, d_pairs, pairs.data(), sizeof(FeatPair) * (int64_t)pairs.size(), s);
+                    if (st) return st;
                     // (1) every source point's nearest target: source-query pairs, folded per job
                     // matrix-core filter + exact recheck (reg_featnn.hip); the VALU search only if its candidate list overflowed
-                    const bool use_mfma = getenv("IBL_FEAT_VALU") == nullptr;      // read per call: the tests compare both searches
+                    const bool use_mfma = getenv("IBL_FEAT_VALU") == nullptr && !tl_force_valu;      // read per call: the tests compare both searches
                     bool over = !use_mfma;
                     if (use_mfma) {
                         st = ibl_feat_search_mfma(ctx, d_pairs, n_pairs0, max_q, src, pair_idx, pair_d2, nullptr, nullptr, 0, pts0, &over, s);
@@ -1381,7 +1435,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 } else if (N > 0) {
                     IBL_HIP_CHECK(hipMemsetAsync(nn, 0, sizeof(int) * (size_t)N, s));
                 }
-                IBL_HIP_CHECK(hipStreamSynchronize(s));     // the group scratch is released here
+                // (the group scratch released here is reused by later kernels of the same stream only: no synchronisation)
             }
             phase("feature search");
             hipLaunchKernelGGL(ibl_mutual_kernel, dim3(J), dim3(256), 0, s, nn, d_job_off, J, 1, 9, corr, n_corr);
@@ -1396,12 +1450,11 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             // that never reach the confidence exit walk all 4 M), rounds grow to RANSAC_TAIL_ROUND so that they still fill the GPU
             const int64_t cap_slots = std::max<int64_t>((int64_t)J * max_round, (int64_t)RANSAC_TAIL_JOBS * RANSAC_TAIL_ROUND);
             const int64_t cap_blk = cap_slots / 256;
-            float4* cp; unsigned char* flags; int *blk_cnt, *blk_off, *list, *n_active;
+            float4* cp; unsigned char* flags; int *blk_cnt, *blk_off, *list;
             IBL_ARENA(cp, float4, 2 * (int64_t)Ns + 2);
             IBL_ARENA(flags, unsigned char, cap_slots);
             IBL_ARENA(blk_cnt, int, cap_blk + 1);
             IBL_ARENA(blk_off, int, cap_blk + 1);
-            IBL_ARENA(n_active, int, 64);
             const int list_cap = (int)std::min<int64_t>(cap_slots / 16 + 65536, (int64_t)1 << 27);
             IBL_ARENA(list, int, list_cap);
             int *e_inl, *e_job; double *e_err2, *e_T;
@@ -1415,59 +1468,72 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             IBL_ARENA(tmp, unsigned char, (int64_t)tmp_bytes + 256);
             hipLaunchKernelGGL(ibl_pack_corr_kernel, dim3(16, J), dim3(256), 0, s, P, d_job_off, J, corr, n_corr, cp);
             IBL_LAUNCH_CHECK();
-            int* active[2];
-            IBL_ARENA(active[0], int, J + 1);
-            IBL_ARENA(active[1], int, J + 1);
-            IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
-            hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist,
-                               active[0], n_active);
+            int *active, *done_flags;
+            IBL_ARENA(active, int, J + 1);
+            IBL_ARENA(done_flags, int, J + 1);
+            hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist, active);
             IBL_LAUNCH_CHECK();
-            int h_active = 0;
-            IBL_HIP_CHECK(hipMemcpyAsync(&h_active, n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-            IBL_HIP_CHECK(hipStreamSynchronize(s));
-            long long walked = 0;
-            int round_size = RANSAC_FIRST_ROUND;
-            int cur = 0;
-            while (walked < ransac_max_iter && h_active > 0) {
-                if (h_active <= RANSAC_TAIL_JOBS && round_size == max_round) round_size = RANSAC_TAIL_ROUND;
+            // Rounds are enqueued without asking the device anything: every per-round kernel finds the round's survivor count in
+            // device memory (the last entry of the block-count scan), and the blocks of a job that has met its confidence bound
+            // leave at once.  The host only looks between GROUPS of rounds -- after the first three (4 k + 32 k + 256 k hypotheses,
+            // where most jobs stop) and then after every two -- to compact the list of running jobs and to stop.
+            auto run_round = [&](int n_act, int round_size) -> int {
                 const int nblk = round_size / 256;
-                const int n_tab = h_active * nblk;          // tables are indexed by (slot in the active list, block)
-                IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)h_active * round_size, s));
+                const int n_tab = n_act * nblk;           // tables are indexed by (slot in the active list, block)
+                IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_act * round_size, s));
                 if (round_size >= 16384)
-                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<16>, dim3(round_size / 16384, h_active), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
+                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<16>, dim3(round_size / 16384, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
                                        (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
-                                       blk_cnt, active[cur]);
+                                       blk_cnt, active);
                 else
-                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<4>, dim3(round_size / 4096, h_active), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
+                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<4>, dim3(round_size / 4096, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
                                        (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
-                                       blk_cnt, active[cur]);
+                                       blk_cnt, active);
                 IBL_LAUNCH_CHECK();
                 IBL_HIP_CHECK(hipMemsetAsync(blk_cnt + n_tab, 0, sizeof(int), s));
                 IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, n_tab + 1, s));
-                int total = 0;
-                IBL_HIP_CHECK(hipMemcpyAsync(&total, blk_off + n_tab, sizeof(int), hipMemcpyDeviceToHost, s));
-                IBL_HIP_CHECK(hipStreamSynchronize(s));
-                if (total > list_cap) return ibl_set_error(IBL_ERR_OVERFLOW, "ransac: %d surviving hypotheses in one round exceed the list capacity %d", total, list_cap);
-                if (total > 0) {
-                    hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, h_active), dim3(256), 0, s, flags, blk_off, round_size, list);
-                    IBL_LAUNCH_CHECK();
-                    hipLaunchKernelGGL(ibl_ransac_transform_kernel, dim3((total + 255) / 256), dim3(256), 0, s, rs, cp, d_job_off, n_corr, active[cur],
-                                       h_active, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total,
-                                       e_job, e_T);
-                    IBL_LAUNCH_CHECK();
-                    hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3((total + 3) / 4), dim3(256), 0, s, cp, d_job_off, n_corr, max_dist, total, e_job,
-                                       e_T, e_inl, e_err2);
-                    IBL_LAUNCH_CHECK();
-                }
-                IBL_HIP_CHECK(hipMemsetAsync(n_active, 0, sizeof(int), s));
-                hipLaunchKernelGGL(ibl_ransac_fold_kernel, dim3(h_active), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99, round_size,
-                                   blk_off, list, e_inl, e_err2, e_T, total, n_active, active[cur], active[cur ^ 1]);
+                const int* total_ptr = blk_off + n_tab;
+                hipLaunchKernelGGL(ibl_ransac_scatter_kernel, dim3(nblk, n_act), dim3(256), 0, s, flags, blk_off, round_size, list, list_cap);
                 IBL_LAUNCH_CHECK();
-                IBL_HIP_CHECK(hipMemcpyAsync(&h_active, n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+                const int sweep = (int)std::min<int64_t>(2048, ((int64_t)list_cap + 255) / 256);
+                hipLaunchKernelGGL(ibl_ransac_transform_kernel, dim3(sweep), dim3(256), 0, s, rs, cp, d_job_off, n_corr, active, n_act, max_dist, 0.9,
+                                   (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, blk_off, list, total_ptr, list_cap, ctx->d_status,
+                                   e_job, e_T);
+                IBL_LAUNCH_CHECK();
+                hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3(4096), dim3(256), 0, s, cp, d_job_off, n_corr, max_dist, total_ptr, list_cap, e_job,
+                                   e_T, e_inl, e_err2);
+                IBL_LAUNCH_CHECK();
+                hipLaunchKernelGGL(ibl_ransac_fold_kernel, dim3(n_act), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99, round_size,
+                                   blk_off, list, e_inl, e_err2, e_T, active);
+                IBL_LAUNCH_CHECK();
+                return IBL_OK;
+            };
+            std::vector<int> h_done(J, 0), h_list;
+            long long walked = 0;
+            int round_size = RANSAC_FIRST_ROUND;
+            int n_act = J;
+            int group = 3;
+            while (walked < ransac_max_iter && n_act > 0) {
+                for (int r = 0; r < group && walked < ransac_max_iter; ++r) {
+                    if (n_act <= RANSAC_TAIL_JOBS && round_size == max_round) round_size = RANSAC_TAIL_ROUND;
+                    st = run_round(n_act, round_size);
+                    if (st) return st;
+                    walked += round_size;
+                    if (round_size < max_round) round_size = std::min(max_round, round_size * 8);
+                }
+                if (walked >= ransac_max_iter) break;
+                hipLaunchKernelGGL(ibl_ransac_done_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, J, done_flags);
+                IBL_LAUNCH_CHECK();
+                IBL_HIP_CHECK(hipMemcpyAsync(h_done.data(), done_flags, sizeof(int) * J, hipMemcpyDeviceToHost, s));
                 IBL_HIP_CHECK(hipStreamSynchronize(s));
-                cur ^= 1;
-                walked += round_size;
-                if (round_size < max_round) round_size = std::min(max_round, round_size * 8);
+                h_list.clear();
+                for (int j = 0; j < J; ++j) if (!h_done[j]) h_list.push_back(j);
+                n_act = (int)h_list.size();
+                if (n_act > 0) {
+                    st = ibl_stage_upload(ctx, active, h_list.data(), sizeof(int) * (int64_t)n_act, s);
+                    if (st) return st;
+                }
+                group = n_act <= RANSAC_TAIL_JOBS ? 1 : 2;
             }
         }
     }
@@ -1505,7 +1571,23 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     }
     std::vector<double> h_means((size_t)J * 6);
     IBL_HIP_CHECK(hipMemcpyAsync(h_means.data(), d_means, sizeof(double) * J * 6, hipMemcpyDeviceToHost, s));
+    int h_status = 0;
+    IBL_HIP_CHECK(hipMemcpyAsync(&h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     IBL_HIP_CHECK(hipStreamSynchronize(s));
+    ibl_stage_reset(ctx);
+    if (h_status & IBL_ST_RANSAC_OVERFLOW)
+        return ibl_set_error(IBL_ERR_OVERFLOW, "ransac: the surviving hypotheses of one round exceed the list capacity");
+    if ((h_status & IBL_ST_FEAT_OVERFLOW) && !tl_force_valu) {
+        // the candidate list of the matrix-core feature search overflowed (results of this pass are unusable): once more with the VALU
+        // search, which has no list
+        tl_force_valu = true;
+        const int st2 = ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
+                                                  job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed,
+                                                  job_id_base, ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out,
+                                                  means_out, T_ransac_out, ransac_stats_out, reuse_stats_out, stream);
+        tl_force_valu = false;
+        return st2;
+    }
     for (int j = 0; j < J; ++j) {
         for (int i = 0; i < 16; ++i) T_out[16 * j + i] = h_is[j].T[i];
         rmse_out[j] = h_is[j].rmse;

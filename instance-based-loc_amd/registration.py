@@ -167,7 +167,7 @@ def instance_features_batch(ctx: RegContext, batch: CloudBatch, voxel_size: floa
     n = max(batch.n, 1)
     normals = torch.empty((n, 4), dtype=torch.float32, device=dev)
     fpfh = torch.empty((n, 33), dtype=torch.float32, device=dev)
-    fpfh_split = torch.empty((n, 96), dtype=torch.bfloat16, device=dev)      # hi | lo parts of every row (matrix-core filter operands)
+    fpfh_split = torch.empty((n, 48), dtype=torch.float16, device=dev)      # the rows once more as fp16 search operands (csrc/reg_featnn.hip)
     fpfh_norm = torch.empty((n,), dtype=torch.float32, device=dev)
     grad = torch.empty((n, 4), dtype=torch.float32, device=dev) if grad_radius > 0 else None
     bbox = np.zeros((max(batch.n_seg, 1), 6), dtype=np.float32)

@@ -196,7 +196,7 @@ def test_instance_features_chunked_equals_single_pass(ctx):
 
 
 def test_matrix_core_feature_search_equals_valu_search(ctx):
-    """the MFMA-filtered nearest-feature search (bf16 hi/lo products + exact recheck) against the full VALU scan it replaces
+    """the MFMA-filtered nearest-feature search (fp16 products with the norms folded in + exact recheck) against the full VALU scan it replaces
     (IBL_FEAT_VALU=1): every output of the registration must be bit-identical -- the filter may only drop rows that cannot be
     the exact minimum.  Includes a degenerate job (a cloud registered onto itself: every distance 0 is an exact tie)."""
     import os
@@ -211,12 +211,16 @@ def test_matrix_core_feature_search_equals_valu_search(ctx):
     jt = [[ids[0], -1, -1], [ids[0], ids[1], -1], [ids[0], ids[1], ids[2]], [8, 0, -1], [0, -1, -1], [7, -1, -1]]
     fd = instance_features_batch(ctx, det, 0.05)
     fm = instance_features_batch(ctx, mem, 0.05, grad_radius=0.15)
-    # the split operands reproduce the rows: hi + lo within 2^-17 relative, norms exact to fp32 rounding
+    # the fp16 search operands: the row to 2^-11 relative, then 8 8 | |x|^2 / 8 as hi + lo | C |x|^2 rounded up | zeros; norms exact to
+    # fp32 rounding
     rows = fm.fpfh[:mem.n].double()
-    rec = fm.fpfh_split[:mem.n, :33].double() + fm.fpfh_split[:mem.n, 48:81].double()
-    assert (rec - rows).abs().max().item() <= 2.0 ** -17 * rows.abs().max().item()
-    assert torch.count_nonzero(fm.fpfh_split[:mem.n, 33:48]).item() == 0
-    assert torch.allclose(fm.fpfh_norm[:mem.n].double(), (rows * rows).sum(1), rtol=1e-5)
+    op = fm.fpfh_split[:mem.n].double()
+    assert ((op[:, :33] - rows).abs() <= 2.0 ** -11 * rows.abs() + 1e-7).all()
+    nrm = fm.fpfh_norm[:mem.n].double()
+    assert torch.allclose(nrm, (rows * rows).sum(1), rtol=1e-5)
+    assert (op[:, 33] == 8).all() and (op[:, 34] == 8).all() and torch.count_nonzero(op[:, 38:]).item() == 0
+    assert ((op[:, 35] + op[:, 36]) * 8 - nrm).abs().max().item() <= 2.0 ** -20 * nrm.max().item()
+    assert (op[:, 37] >= 1.0e-3 * nrm * (1 - 1e-6)).all() and (op[:, 37] <= 1.0e-3 * nrm * (1 + 2.0 ** -9) + 1e-6).all()
     outs = []
     for env in ({}, {"IBL_FEAT_VALU": "1"}, {"IBL_FEAT_CAND_CAP": "100"}):        # matrix cores | VALU scan | overflow -> fallback
         os.environ.update(env)
