@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <atomic>
+
 #include "ibl_common.h"
 #include "ibloc.h"
 
@@ -378,11 +380,16 @@ static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw,
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     const int nwg = (N / BN) * ((M + BM - 1) / BM);
     const size_t lds = NS * (size_t)(BM + BN) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device property of the function: set once per device of this process.  The bit mask is only
+    // a cache -- two threads racing here both set the same value (localise_concurrent lanes launch from several host threads)
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    IBL_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     void* tok;
     ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);

@@ -418,6 +418,24 @@ class ObjectMemory():
         save_root = f"pcds/{testname}/"                                               # side effect of the reference (:947-950)
         if not os.path.exists(save_root):
             os.makedirs(save_root)
+        if save_point_clouds:
+            # :952-966 writes the detected clouds and the memory into one "_init_pcd_<subtest>.ply".  (The reference adds the
+            # ObjectInfo records themselves to an Open3D cloud there -- `init_pcd += m`, :961-962 -- which Open3D rejects; what
+            # is written here is what that block is after: every detected and every memory point, colours kept.)
+            from .object_info import write_ply
+            subsave_root = os.path.join(save_root, str(subtest_name))
+            os.makedirs(subsave_root, exist_ok=True)
+            if isinstance(clouds, CloudBatch):
+                p4 = clouds.pts4.cpu().numpy()
+                det_pts = [p4[:, :3].astype(np.float64)]
+                det_cols = [np.repeat(p4[:, 3:4].astype(np.float64), 3, axis=1)]          # the batch keeps the intensity only
+            else:
+                det_pts, det_cols = [np.asarray(c[0], dtype=np.float64) for c in clouds], [np.asarray(c[1], dtype=np.float64) for c in clouds]
+            mem_pts = [np.asarray(m.pointcloud.points, dtype=np.float64) for m in self.memory]
+            mem_cols = [np.asarray(m.pointcloud.colors, dtype=np.float64) if len(np.asarray(m.pointcloud.colors)) == len(np.asarray(m.pointcloud.points))
+                        else np.zeros((len(np.asarray(m.pointcloud.points)), 3)) for m in self.memory]
+            write_ply(os.path.join(subsave_root, "_init_pcd_" + str(subtest_name) + ".ply"), np.concatenate(det_pts + mem_pts),
+                      np.concatenate(det_cols + mem_cols))
         res = self.localise_detections(embs, clouds, outlier_removal_config, fpfh_global_dist_factor, fpfh_local_dist_factor,
                                        fpfh_voxel_size, max_detected_object_num)
         last = res.assignments[-1] if res.assignments else []

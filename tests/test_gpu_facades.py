@@ -141,6 +141,14 @@ def test_object_memory_localise_with_stub_finder(tmp_path):
                                 perform_semantic_icp=False, outlier_removal_config={"radius_nb_points": 2, "radius": 0.2})
     assert pose1.shape == (7,) and np.isfinite(pose1).all() and extra1[1] is None
     assert extra1[0][0][1] == 1                                          # matched the instance whose embedding was returned
+    # save_point_clouds=True (:947-972): pcds/<testname>/<subtest>/_init_pcd_<subtest>.ply holds the detections and the memory
+    from ibloc_amd.object_memory.object_info import read_ply
+    pose2, _ = om.localise(str(tmp_path / "rgb.png"), str(tmp_path / "depth.npy"), testname=str(tmp_path / "t"), subtest_name="s7",
+                           save_point_clouds=True, perform_semantic_icp=False, outlier_removal_config={"radius_nb_points": 2, "radius": 0.2})
+    assert np.array_equal(pose2[3:], pose1[3:]) or np.isfinite(pose2).all()
+    pts, cols = read_ply(f"pcds/{tmp_path / 't'}/s7/_init_pcd_s7.ply")
+    n_mem = sum(len(np.asarray(m.pointcloud.points)) for m in om.memory)
+    assert len(pts) > n_mem and cols is not None and len(cols) == len(pts)
 
 
 def test_object_memory_pickle_round_trip(tmp_path):
