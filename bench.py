@@ -72,26 +72,34 @@ def host_cores():
 
 
 class Crops:
-    """Per-instance base crops and their noisy variants (memory views and query crops), for the ViT encoders (224^2 RGB u8) and for
-    DATOR (256x128 RGB u8 + 64x32 float depth in metres)."""
+    """Per-instance base crops (generated on first use) and their noisy variants (memory views and query crops), for the ViT encoders
+    (224^2 RGB u8) and for DATOR (256x128 RGB u8 + 64x32 float depth in metres)."""
 
-    def __init__(self, model, n_inst, rng):
+    def __init__(self, model, seed):
         self.dator = model == "dator"
-        h, w = (256, 128) if self.dator else (224, 224)
-        self.base = np.stack([smooth_image(rng, h, w) for _ in range(n_inst)])
-        if self.dator:
-            self.depth = np.stack([0.3 + 7.7 * smooth_image(rng, 64, 32, 1)[:, :, 0] for _ in range(n_inst)]).astype(np.float32)
+        self.hw = (256, 128) if self.dator else (224, 224)
+        self.seed = seed
+        self._base, self._depth = {}, {}
+
+    def base(self, k):
+        if k not in self._base:
+            r = np.random.default_rng([self.seed, int(k)])
+            self._base[k] = smooth_image(r, *self.hw)
+            if self.dator:
+                self._depth[k] = (0.3 + 7.7 * smooth_image(r, 64, 32, 1)[:, :, 0]).astype(np.float32)
+        return self._base[k]
 
     def variants(self, ids, r, device):
         import torch
-        out = np.empty((len(ids),) + self.base.shape[1:], dtype=np.uint8)
+        out = np.empty((len(ids),) + self.hw + (3,), dtype=np.uint8)
         for i, k in enumerate(ids):
-            v = self.base[k] + r.normal(0, 0.03, size=self.base[k].shape).astype(np.float32)
+            b = self.base(k)
+            v = b + r.normal(0, 0.03, size=b.shape).astype(np.float32)
             out[i] = np.clip(v * 255.0, 0, 255).astype(np.uint8)
         rgb = torch.from_numpy(out).to(device)
         if not self.dator:
             return rgb
-        d = self.depth[np.asarray(ids)] + r.normal(0, 0.02, size=(len(ids), 64, 32)).astype(np.float32)
+        d = np.stack([self._depth[k] for k in ids]) + r.normal(0, 0.02, size=(len(ids), 64, 32)).astype(np.float32)
         return (rgb, torch.from_numpy(d.astype(np.float32)).to(device))
 
 
@@ -115,12 +123,35 @@ def build_workload(args, rank, world_size, device):
     world = SynthWorld(args.memory, pts_per_object=max(args.points, 16), E=args.views, D=dim, seed=21,
                        sample_points=args.register)
     rng = np.random.default_rng(21)
-    crops = Crops(args.model, args.memory, rng)
-    mem_emb = []
-    ids_all = np.repeat(np.arange(args.memory), args.views)
+    crops = Crops(args.model, 21)
+    # query batches first (distinct per step and per rank): they tell which instances are ever looked at
+    frames = []
+    frng = np.random.default_rng(1000 + rank)
+    for step in range(args.warmup + args.steps):
+        frames.append([world.make_frame(frng, q=args.q, pts_per_object=args.points, with_clouds=args.register) for _ in range(args.frames)])
+    # memory embeddings = the encoder's embeddings of E noisy views of every instance.  An embedding-only memory of 50 000
+    # instances (config C4) would need 200 000 synthetic crops that no query ever looks at: there only the instances that occur in
+    # a query frame (of any rank) are embedded, the others keep the generator's random unit embeddings -- throughput is unaffected
+    # (the match streams every row either way), the accuracy fields then describe the embedded instances only
+    embed_ids = np.arange(args.memory)
+    if not args.register and args.memory > 20000:
+        seen = set()
+        for r in range(world_size):
+            rr = np.random.default_rng(1000 + r)
+            for step in range(args.warmup + args.steps):
+                for _ in range(args.frames):
+                    seen.update(world.make_frame(rr, q=args.q, pts_per_object=args.points, with_clouds=False)["ids"])
+        embed_ids = np.array(sorted(seen))
+    mem_emb = world.embeddings.astype(np.float32).copy()
+    mem_emb /= np.linalg.norm(mem_emb, axis=-1, keepdims=True)
+    ids_all = np.repeat(embed_ids, args.views)
+    got = []
     for i in range(0, len(ids_all), 256):
-        mem_emb.append(enc.embed(crops.variants(ids_all[i:i + 256], rng, device)).cpu().numpy())
-    mem_emb = np.concatenate(mem_emb).reshape(args.memory, args.views, -1)
+        got.append(enc.embed(crops.variants(ids_all[i:i + 256], rng, device)).cpu().numpy())
+    got = np.concatenate(got).reshape(len(embed_ids), args.views, -1)
+    if len(embed_ids) < args.memory:
+        mem_emb = mem_emb * np.linalg.norm(got, axis=-1).mean()           # the scale of the encoder's (un-normalised) outputs
+    mem_emb[embed_ids] = got
     ctx = RegContext(int(args.arena_gb * (1 << 30)))
     shard = (rank, world_size) if args.shard_memory and world_size > 1 else None
     mem = MemoryShard(ctx, list(mem_emb), world.points if args.register else None, colors=world.colors if args.register else None,
@@ -128,13 +159,11 @@ def build_workload(args, rank, world_size, device):
     # host cores are shared by the ranks of the node: the assignment search takes its share, at most 16 threads
     cores = host_cores()
     eng = LocaliseEngine(mem, enc, assign_threads=max(1, min(16, cores // max(1, world_size))))
-    # query batches (distinct per step and per rank), device resident
+    # query batches, device resident
     batches = []
-    frng = np.random.default_rng(1000 + rank)
-    for step in range(args.warmup + args.steps):
+    for fl in frames:
         clouds, ints, crop_ids, qs, poses, ids = [], [], [], [], [], []
-        for _ in range(args.frames):
-            f = world.make_frame(frng, q=args.q, pts_per_object=args.points, with_clouds=args.register)
+        for f in fl:
             for (p, c) in f["clouds"]:
                 clouds.append(p)
                 ints.append(intensity_from_colors(c))
