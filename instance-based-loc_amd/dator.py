@@ -62,6 +62,7 @@ def fold_lora(w: dict) -> dict:
             delta = (w[f"l{l}.lora_down"].astype(np.float64) @ w[f"l{l}.lora_up"].astype(np.float64)).T.astype(np.float32)   # (2304, 768)
             for i, n in enumerate("qkv"):
                 out[f"l{l}.{n}.w"] = w[f"l{l}.{n}.w"] + delta[i * 768:(i + 1) * 768]
+            del out[f"l{l}.lora_down"], out[f"l{l}.lora_up"]          # folded: nothing downstream may add the term again
     return out
 
 

@@ -65,12 +65,13 @@ def interpolate_pos(pos: torch.Tensor, stored_grid, grid, mode: str) -> torch.Te
 
 
 @torch.no_grad()
-def vit_forward(weights: dict, cfg, pixel_values: np.ndarray, all_tokens=False) -> np.ndarray:
+def vit_forward(weights: dict, cfg, pixel_values: np.ndarray, all_tokens=False, device="cpu") -> np.ndarray:
     """pixel_values (B, 3, H, W) float32 -> (B, out_dim) float32 (or (B, T, D) when all_tokens).
-    cfg is an ibloc_amd.vit.VitConfig (plain data)."""
+    cfg is an ibloc_amd.vit.VitConfig (plain data).  device: where torch evaluates this fp32 restatement ("cuda" lets the parity
+    tests embed tens of thousands of crops; gfx950 has no reduced-precision fp32 matmul mode, the arithmetic stays fp32)."""
     F = torch.nn.functional
-    w = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in weights.items()}
-    x = torch.from_numpy(np.asarray(pixel_values, dtype=np.float32))
+    w = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v, dtype=np.float32))).to(device) for k, v in weights.items()}
+    x = torch.from_numpy(np.asarray(pixel_values, dtype=np.float32)).to(device)
     B = x.shape[0]
     x = F.conv2d(x, w["patch.w"], w.get("patch.b"), stride=cfg.patch)           # (B, D, gh, gw)
     x = x.flatten(2).transpose(1, 2)
@@ -99,18 +100,18 @@ def vit_forward(weights: dict, cfg, pixel_values: np.ndarray, all_tokens=False) 
     if all_tokens:
         if cfg.final_ln:
             x = F.layer_norm(x, (cfg.dim,), w["ln_f.g"], w["ln_f.b"], cfg.ln_eps)
-        return x.numpy()
+        return x.cpu().numpy()
     c = x[:, 0]
     if cfg.final_ln:
         c = F.layer_norm(c, (cfg.dim,), w["ln_f.g"], w["ln_f.b"], cfg.ln_eps)
     if cfg.proj_dim:
         c = c @ w["proj.w"].t()
-    return c.numpy()
+    return c.cpu().numpy()
 
 
-def embed_crops(weights: dict, cfg, recipe, crops, l2_normalize=False) -> np.ndarray:
+def embed_crops(weights: dict, cfg, recipe, crops, l2_normalize=False, device="cpu") -> np.ndarray:
     px = np.stack([preprocess_crop(c, recipe) for c in crops])
-    out = vit_forward(weights, cfg, px)
+    out = vit_forward(weights, cfg, px, device=device)
     if l2_normalize:                       # clip_features /= clip_features.norm(...), embeddings.py:48
         out = out / np.linalg.norm(out, axis=-1, keepdims=True)
     return out
