@@ -123,8 +123,11 @@ def test_consolidation_matches_reference_transcript():
             want = bo.recluster_objects_with_dbscan(want, 0.08, 20)
         _same_memory(mem, want)
         assert 8 <= len(mem.memory) <= 16 and [o.id for o in mem.memory] == list(range(len(mem.memory)))
-        with pytest.raises(NotImplementedError):
-            mem._recluster_IoU(0.3)                                      # the object-aligned IoU is not part of this build
+        # the default measure of _recluster_IoU is the object-aligned box IoU (IoU_ops.py:97-145), as in the reference's driver
+        from ibloc_amd.utils.IoU_ops import calculate_obj_aligned_3d_IoU
+        mem._recluster_IoU(0.3)
+        want = bo.recluster_IoU(want, 0.3, calculate_obj_aligned_3d_IoU)
+        _same_memory(mem, want)
         mem._ctx.close()
     # recluster_via_agglomerative_clustering (:379-437): embedding clusters only
     mem = ObjectMemory(device="cuda", get_embeddings_func=lambda **kw: None, log_enabled=False, arena_bytes=1 << 30)

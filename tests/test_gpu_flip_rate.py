@@ -45,6 +45,10 @@ def _embed_both(enc, w, cfg, crops_u8):
 
 @pytest.mark.parametrize("M,F", [(1000, 64), (10000, 64)], ids=["C2", "T"])
 def test_assignment_flip_rate_fp16_encoder_vs_fp32_oracle(M, F):
+    import os
+    if M > 1000 and not os.environ.get("IBL_FULL_PARITY"):
+        pytest.skip("the 10 000-instance case embeds 2 x 40 000 crops (3 minutes): IBL_FULL_PARITY=1; its output is committed "
+                    "under profiles/r02/parity_flip_rate.txt")
     from ibloc_amd import vit as V
     from ibloc_amd.engine import LocaliseEngine, MemoryShard
     from ibloc_amd.registration import RegContext

@@ -116,17 +116,26 @@ def test_c5_registration_of_100k_point_objects_matches_oracle():
         cleaned.append(p[k])
         ccols.append(c[k])
     assert res.n_clean == sum(len(c) for c in cleaned) and res.n_clean > 1.5 * N
-    # the oracle on the two-object assignment only (the 2 x 200 000-point job; the single-object ones follow the same code)
-    two = [a for a in assns if len(a) == 2][:1]
-    k2 = assns.index(two[0])
-    pose_o, recs, _ = ro.localise_from_assignments(cleaned, ccols, w.points, w.colors, two, 0.05, 1.5, 1.5, seed=13, job_base=k2,
+    # the oracle on the single-object assignment (100 000 source x 100 000 target points; its feature matching alone is 2 x 10^10
+    # 33-d distances on the host), the two-object job (2 x 200 000 points) against the device's own uncached schedule and the truth
+    one = [a for a in assns if len(a) == 1][:1]
+    k1 = assns.index(one[0])
+    pose_o, recs, _ = ro.localise_from_assignments(cleaned, ccols, w.points, w.colors, one, 0.05, 1.5, 1.5, seed=13, job_base=k1,
                                                    stale_means=False)
-    a, b = res.records[k2], recs[0]
+    a, b = res.records[k1], recs[0]
     dt = np.linalg.norm(a["T_global"][:3, 3] - b["T_global"][:3, 3])
     dr = _deg(a["T_global"][:3, :3], b["T_global"][:3, :3])
     print(f"100k-point objects: vs oracle {dt:.2e} m / {dr:.2e} deg; fitness {a['fitness']:.4f} / {b['fitness']:.4f}; "
           f"full fitness {a['full_fitness']:.4f} / {b['full_fitness']:.4f}")
     assert dt <= 0.01 and dr <= 0.5 and abs(a["fitness"] - b["fitness"]) < 5e-3 and abs(a["full_fitness"] - b["full_fitness"]) < 5e-3
+    eng.reuse_features = False               # the reference's schedule: features of every job recomputed on its concatenated clouds
+    res2 = eng.localise_batch(det, [2], det_emb=f["det_emb"], fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5,
+                              seed=13)[0]
     P = f["pose"]
-    assert np.linalg.norm(a["T_global"][:3, 3] - P[:3, 3]) < 0.6 and np.radians(_deg(a["T_global"][:3, :3], P[:3, :3])) < 0.3
+    for k, (x, y) in enumerate(zip(res.records, res2.records)):
+        assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["ransac_stats"], y["ransac_stats"]), k      # cached == uncached, bit for bit
+    two = [k for k, a_ in enumerate(assns) if len(a_) == 2][0]
+    G = res.records[two]["T_global"]
+    assert np.linalg.norm(G[:3, 3] - P[:3, 3]) < 0.6 and np.radians(_deg(G[:3, :3], P[:3, :3])) < 0.3
+    assert eng.check_status() & 1 == 0
     ctx.close()
