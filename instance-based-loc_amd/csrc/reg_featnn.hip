@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "reg_common.h"
@@ -60,7 +61,7 @@ __device__ __forceinline__ void fm_split_norm(float v, _Float16* h, _Float16* l)
 // fetched into registers one chunk ahead); every wave holds its 32 queries as the B operand in registers.
 template <int PASS, bool INDEXED>
 __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __restrict__ pairs, FeatSources src, float* __restrict__ up,
-                                                            FmCand* __restrict__ cand, int* __restrict__ n_cand, int cand_cap,
+                                                            FmCand* __restrict__ cand, unsigned long long* __restrict__ n_cand, int cand_cap,
                                                             const int* __restrict__ need_pos, const int* __restrict__ need_list, int out0) {
     const FeatPair P = pairs[blockIdx.y];
     int n_q = P.qcnt, l0 = 0;
@@ -123,13 +124,15 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
     int qcount = 0;                                  // wave-uniform
     auto flush = [&]() {
         if (qcount == 0) return;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(n_cand, qcount);
+        // 64-bit count: a database with thousands of near-identical rows (the interior of a large planar face) passes that many rows
+        // per query, 10^10 per instance pair at 100 000 points -- a 32-bit counter wrapped and the slots below went out of bounds
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_cand, (unsigned long long)qcount);
         base = __shfl(base, 0, 64);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < qcount; i += 64)
-            if (base + i < cand_cap) { const int2 e = queue[wave][i]; cand[base + i] = FmCand{(int)blockIdx.y, e.x, e.y, 0}; }
+            if (base + (unsigned long long)i < (unsigned long long)cand_cap) { const int2 e = queue[wave][i]; cand[base + i] = FmCand{(int)blockIdx.y, e.x, e.y, 0}; }
         __builtin_amdgcn_wave_barrier();
         qcount = 0;
     };
@@ -195,9 +198,9 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
 // thread per candidate: the exact fp32 chain (the summation order of the VALU search / oracle: rows are stored in matching
 // order, terms 0..32), folded into the lexicographic minimum of (distance, database index)
 __global__ __launch_bounds__(256) void ibl_feat_exact_kernel(const FeatPair* __restrict__ pairs, FeatSources src, const FmCand* __restrict__ cand,
-                                                             const int* __restrict__ n_cand, int cand_cap,
+                                                             const unsigned long long* __restrict__ n_cand, int cand_cap,
                                                              unsigned long long* __restrict__ best) {
-    const int total = min(*n_cand, cand_cap);
+    const int total = (int)min(*n_cand, (unsigned long long)cand_cap);
     for (int c = blockIdx.x * 256 + threadIdx.x; c < total; c += gridDim.x * 256) {
         const FmCand K = cand[c];
         const FeatPair P = pairs[K.pair];
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(256) void ibl_feat_exact_kernel(const FeatPair* __r
 
 __global__ __launch_bounds__(256) void ibl_feat_finish_kernel(const unsigned long long* __restrict__ best, int64_t i0, int64_t n,
                                                               int* __restrict__ pair_idx, float* __restrict__ pair_d2,
-                                                              const int* __restrict__ n_cand, int cand_cap, int* __restrict__ status) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *n_cand > cand_cap) atomicOr(status, IBL_ST_FEAT_OVERFLOW);
+                                                              const unsigned long long* __restrict__ n_cand, int cand_cap, int* __restrict__ status) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *n_cand > (unsigned long long)cand_cap) atomicOr(status, IBL_ST_FEAT_OVERFLOW);
     const int64_t i = i0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= i0 + n) return;
     const unsigned long long k = best[i];
@@ -231,14 +234,14 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
     ArenaMark mark(ctx);
     int cand_cap = (int)std::min<int64_t>(out_count * 8 + 65536, (int64_t)1 << 27);
     if (const char* e = getenv("IBL_FEAT_CAND_CAP")) cand_cap = std::max(1, atoi(e));      // tests: force the overflow fallback
-    float* up; FmCand* cand; int* n_cand; unsigned long long* best;
+    float* up; FmCand* cand; unsigned long long* n_cand; unsigned long long* best;
     IBL_ARENA(up, float, out_count + 64);
     IBL_ARENA(cand, FmCand, cand_cap);
-    IBL_ARENA(n_cand, int, 64);
+    IBL_ARENA(n_cand, unsigned long long, 32);
     IBL_ARENA(best, unsigned long long, out_count + 64);
     float* up0 = up - out0;                      // kernels index the output space of all pairs; this region starts at out0
     unsigned long long* best0 = best - out0;
-    IBL_HIP_CHECK(hipMemsetAsync(n_cand, 0, sizeof(int), s));
+    IBL_HIP_CHECK(hipMemsetAsync(n_cand, 0, sizeof(unsigned long long), s));
     IBL_HIP_CHECK(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * (size_t)out_count, s));
     const bool indexed = need_pos != nullptr;
     for (int p0 = 0; p0 < n_pairs; p0 += 32768) {
@@ -254,6 +257,12 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
             hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, false>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0);
         }
         IBL_LAUNCH_CHECK();
+    }
+    if (getenv("IBL_TIMING") && atoi(getenv("IBL_TIMING")) >= 2) {
+        unsigned long long h = 0;
+        const hipError_t e = hipMemcpy(&h, n_cand, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[reg-dbg] mfma passes done: %s; candidates %llu of cap %d, out_count %lld, pairs %d, max_q %d\n", hipGetErrorString(e), h, cand_cap,
+                (long long)out_count, n_pairs, max_q);
     }
     hipLaunchKernelGGL(ibl_feat_exact_kernel, dim3(2048), dim3(256), 0, s, d_pairs, src, cand, n_cand, cand_cap, best0);
     IBL_LAUNCH_CHECK();

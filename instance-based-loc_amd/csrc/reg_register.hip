@@ -1016,6 +1016,12 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     const bool timing = getenv("IBL_TIMING") != nullptr;
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t_prev = now();
+    auto dbg = [&](const char* what) {          // IBL_TIMING=2: synchronise after every launch group of the search phase
+        static const bool on = getenv("IBL_TIMING") && atoi(getenv("IBL_TIMING")) >= 2;
+        if (!on) return;
+        const hipError_t e = hipStreamSynchronize(s);
+        fprintf(stderr, "[reg-dbg] %-36s %s\n", what, hipGetErrorString(e));
+    };
     auto phase = [&](const char* what) {
         if (!timing) return;
         (void)hipStreamSynchronize(s);
@@ -1378,10 +1384,12 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                     // matrix-core filter + exact recheck (reg_featnn.hip); the VALU search only if its candidate list overflowed
                     const bool use_mfma = getenv("IBL_FEAT_VALU") == nullptr && !tl_force_valu;      // read per call: the tests compare both searches
                     bool over = !use_mfma;
+                    dbg("plan uploads");
                     if (use_mfma) {
                         st = ibl_feat_search_mfma(ctx, d_pairs, n_pairs0, max_q, src, pair_idx, pair_d2, nullptr, nullptr, 0, pts0, &over, s);
                         if (st) return st;
                     }
+                    dbg("forward search");
                     for (int p0 = 0; over && p0 < n_pairs0; p0 += 32768) {
                         const unsigned np = (unsigned)std::min(32768, n_pairs0 - p0);
                         hipLaunchKernelGGL(ibl_feat_pair_nn_kernel<false>, dim3((max_q + 255) / 256, np), dim3(256), 0, s, d_pairs + p0, src, pair_idx,
@@ -1393,6 +1401,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                                            J, 0, Ns, nn);
                         IBL_LAUNCH_CHECK();
                     }
+                    dbg("forward fold");
                     // (2) the reverse search only for the target points that were matched (a third to a half of them): flag,
                     //     scan, list, search the listed queries; the other targets keep d2 = +inf and are never read
                     const int n1 = (int)(pair_pts - pts0);
@@ -1414,6 +1423,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                         IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, need, need_pos, n1 + 1, s));
                         hipLaunchKernelGGL(ibl_feat_need_list_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, need, need_pos, n1, need_list);
                         IBL_LAUNCH_CHECK();
+                        dbg("need list");
                         over = !use_mfma;
                         if (use_mfma) {
                             st = ibl_feat_search_mfma(ctx, d_pairs + n_pairs0, n_pairs1, max_q, src, pair_idx, pair_d2, need_pos, need_list, (int)pts0, n1,
@@ -1427,11 +1437,13 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                             IBL_LAUNCH_CHECK();
                         }
                     }
+                    dbg("reverse search");
                     if (N > Ns) {
                         hipLaunchKernelGGL(ibl_feat_fold_kernel, dim3((N - Ns + 255) / 256), dim3(256), 0, s, d_sides, d_pairs, pair_idx, pair_d2, d_job_off,
                                            J, Ns, N, nn);
                         IBL_LAUNCH_CHECK();
                     }
+                    dbg("reverse fold");
                 } else if (N > 0) {
                     IBL_HIP_CHECK(hipMemsetAsync(nn, 0, sizeof(int) * (size_t)N, s));
                 }

@@ -27,13 +27,13 @@ class Primitive:
 
 
 class SynthObject:
-    def __init__(self, rng, world_center, extent=(0.15, 0.6)):
+    def __init__(self, rng, world_center, extent=(0.15, 0.6), kinds=(0, 1)):
         n_prim = int(rng.integers(3, 7))
         self.prims = []
         spread = 0.4 * extent[1] / 1.5          # primitive centres stay inside the object's largest extent
         for _ in range(n_prim):
             ext = rng.uniform(extent[0], extent[1], size=3)
-            self.prims.append(Primitive(int(rng.integers(0, 2)), rng.uniform(-spread, spread, size=3), ext / 2,
+            self.prims.append(Primitive(int(kinds[int(rng.integers(0, len(kinds)))]), rng.uniform(-spread, spread, size=3), ext / 2,
                                         Rotation.random(random_state=rng).as_matrix()))
         self.world_center = np.asarray(world_center, dtype=np.float64)
         self.phi = rng.uniform(0, 2 * np.pi, size=3)
@@ -71,7 +71,7 @@ class SynthObject:
 class SynthWorld:
     """M objects on a jittered grid (spacing 2.5 m), E embeddings per instance of dimension D."""
 
-    def __init__(self, M, pts_per_object=5000, E=4, D=768, seed=0, spacing=2.5, extent=(0.15, 0.6), sample_points=True):
+    def __init__(self, M, pts_per_object=5000, E=4, D=768, seed=0, spacing=2.5, extent=(0.15, 0.6), sample_points=True, kinds=(0, 1)):
         rng = np.random.default_rng(seed)
         self.rng = rng
         self.M, self.E, self.D = M, E, D
@@ -81,7 +81,7 @@ class SynthWorld:
         for j in range(M):
             gx, gy = j % side, j // side
             c = np.array([gx * spacing, gy * spacing, 0.0]) + np.append(rng.uniform(-0.3, 0.3, size=2), rng.uniform(0.0, 1.0))
-            self.objects.append(SynthObject(rng, c, extent))
+            self.objects.append(SynthObject(rng, c, extent, kinds))
         self.points = []
         self.colors = []
         for o in (self.objects if sample_points else []):       # embedding-only memories (BASELINE configs[3]) hold no clouds
