@@ -153,12 +153,16 @@ def build_workload(args, rank, world_size, device):
         mem_emb = mem_emb * np.linalg.norm(got, axis=-1).mean()           # the scale of the encoder's (un-normalised) outputs
     mem_emb[embed_ids] = got
     ctx = RegContext(int(args.arena_gb * (1 << 30)))
-    shard = (rank, world_size) if args.shard_memory and world_size > 1 else None
+    comm = None
+    if args.shard_memory and args.comm == "rccl":            # the library's own RCCL communicator instead of torch.distributed's group
+        from ibloc_amd.parallel import RcclComm
+        comm = RcclComm() if world_size > 1 else RcclComm.single()
+    shard = (rank, world_size) if args.shard_memory and (world_size > 1 or comm is not None) else None
     mem = MemoryShard(ctx, list(mem_emb), world.points if args.register else None, colors=world.colors if args.register else None,
                       device=device, shard=shard)
     # host cores are shared by the ranks of the node: the assignment search takes its share, at most 16 threads
     cores = host_cores()
-    eng = LocaliseEngine(mem, enc, assign_threads=max(1, min(16, cores // max(1, world_size))))
+    eng = LocaliseEngine(mem, enc, assign_threads=max(1, min(16, cores // max(1, world_size))), rows_cap=args.frames * 7, comm=comm)
     # query batches, device resident
     batches = []
     for fl in frames:
@@ -262,6 +266,8 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="run the steps back to back instead of pipelined")
     ap.add_argument("--shard-memory", action="store_true", help="shard the embedding memory by instance range over the ranks "
                     "(per-shard candidate top-k + RCCL all-gather) instead of replicating it")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"], help="transport of the --shard-memory collectives: "
+                    "torch.distributed's nccl (= RCCL) group, or the library's own RCCL communicator (ibl_comm_*)")
     args = ap.parse_args()
     preset = CONFIGS[args.config]
     for k in ("model", "memory", "points"):
@@ -392,7 +398,7 @@ def main():
             "config": {"workload": f"{args.config}: {args.model} {crop_desc} (Q={args.q}), {args.memory}-instance memory (E={args.views}), {stages}",
                        "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
                        "points_per_object": args.points,
-                       "parallelism": f"frames-dp{world_size}" + ("+memory-shard%d" % world_size if args.shard_memory and world_size > 1 else "")},
+                       "parallelism": f"frames-dp{world_size}" + ("+memory-shard%d(%s)" % (world_size, args.comm) if args.shard_memory else "")},
             # `roofline`: HIP events around every GEMM launch of the timed region.  With pipelined steps the embed stream shares the
             # device with the registration kernels of the previous step, so a launch's duration there is not the kernel's own
             # speed; `roofline_isolated` is the same measurement over the launches of one extra step run alone afterwards.

@@ -15,8 +15,12 @@
  *     torch.Tensor.data_ptr(); pointers marked [host] are host pointers.  Workspace sizes come
  *     from the *_workspace_bytes() queries.  The library never allocates persistent device memory.
  *   - all launches are asynchronous on the hipStream_t passed as `void* stream`
- *     (torch.cuda.current_stream().cuda_stream); there is no hidden synchronisation unless a
- *     function's comment says it returns host results.
+ *     (torch.cuda.current_stream().cuda_stream).  Functions whose results are DEVICE arrays (embed, match, candidate selection)
+ *     never synchronise.  Functions that return HOST results synchronise the stream -- how often is stated per function:
+ *     ibl_radius_outlier_batch 1 (grid table size), ibl_instance_features_batch 2 (bounding boxes; end),
+ *     ibl_register_batch_cached 2-4 (one per group of RANSAC rounds -- most calls need one -- plus the results; one more when
+ *     instances of a job lie within the influence radius of each other), ibl_evaluate_batch 1, ibl_memgrid_build 2 (once per
+ *     memory).  Plan tables are staged through pinned host memory of the registration context, so uploads never wait.
  *   - plain C types only; no torch types in any signature.
  */
 #ifndef IBLOC_H
@@ -191,6 +195,25 @@ int ibl_closest_similarity(const float* det, int64_t n_query, const float* mem, 
                            const int32_t* emb_offsets, int64_t n_inst, int dim, float* out_sims,
                            uint16_t* out_aug, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Per-row two-ended candidate selection on the fp16 rows `aug` ([sims | 1], ld >= n_cols + 1 halves per row): the k_hi largest and
+ * the k_lo smallest of the first n_cols entries of every row under the total order (value, then lower column first) -- the order
+ * np.argmax's tie rule induces in utils/similarity_volume.py:219-225 -- sorted, as
+ *   out_val [dev] n_rows x (k_hi + k_lo) IEEE binary16 bits, out_idx [dev] n_rows x (k_hi + k_lo) int32 = index_base + column,
+ *   out_cnt [dev] n_rows x 2 int32 = (entries of the high list, entries of the low list).
+ * A row with n_cols <= k_hi + k_lo is returned whole in the high list (count n_cols, 0).  k_hi, k_lo <= 256.  Only these lists leave
+ * the GPU (8 bytes per entry instead of the 2 (M + 1)-byte row) or cross xGMI when the memory is sharded by instance range
+ * (index_base = first instance of the shard).  ibl_assign_candidates runs the assignment search on them. */
+int ibl_topk_select(const uint16_t* aug, int64_t n_rows, int64_t ld, int n_cols, int k_hi, int k_lo, int index_base,
+                    uint16_t* out_val, int32_t* out_idx, int32_t* out_cnt, void* stream);
+
+/* ibl_closest_similarity + ibl_topk_select in one call (SURVEY §8b `ibl_match_topk`): query rows against this rank's memory rows,
+ * the candidates of every row with GLOBAL instance indices.  out_aug [dev] n_query x (n_inst + 1) or NULL (kept in the workspace).
+ * Replaces object_memory/object_memory.py:933-936 and the cast of utils/similarity_volume.py:13-18 for a memory shard. */
+int64_t ibl_match_topk_workspace_bytes(int64_t n_query, int64_t n_mem_rows, int64_t n_inst);
+int ibl_match_topk(const float* det, int64_t n_query, const float* mem, int64_t n_mem_rows, const int32_t* emb_offsets, int64_t n_inst,
+                   int dim, int k_hi, int k_lo, int index_base, uint16_t* out_val, int32_t* out_idx, int32_t* out_cnt, uint16_t* out_aug,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* assign: exact similarity-volume search                                   */
 /* ------------------------------------------------------------------------------------------ */
@@ -209,6 +232,41 @@ int ibl_assign_batch(const uint16_t* aug_half, const int32_t* q_per_frame, int n
                      int M, int num_per_length, int32_t* out_assn, int32_t* out_len, int32_t* out_count,
                      int max_assn, int n_threads);
 
+/* The same search on per-row candidate lists (ibl_topk_select / ibl_match_topk, possibly the union of the lists of several memory
+ * shards after the all-gather): row r has cand_cnt[r] entries (value bits, global column) at cand_val / cand_idx + r * cand_stride,
+ * in any order; frame f owns the rows row_first[f] .. row_first[f] + q_per_frame[f] - 1 (q <= 7).  M_total = instances of the whole
+ * memory; k_hi / k_lo = the list sizes every producer used (they define what a producer may have dropped: entries between its
+ * k_lo-th smallest and k_hi-th largest).  The search runs on the union of the rows' candidate columns and PROVES per frame that no
+ * dropped entry could have reached the k-th best cell of any sub-volume (the chained fp16 product is monotone in every coordinate,
+ * so its maximum over the dropped range is attained at a corner: csrc/assign.cpp).  out_exact[f] = 1: the list equals
+ * ibl_assign_batch on the full rows; 0: the proof failed (ties at the candidate threshold) and the caller redoes the frame on
+ * full rows.  All pointers [host]. */
+int ibl_assign_candidates(const uint16_t* cand_val, const int32_t* cand_idx, const int32_t* cand_cnt, int64_t cand_stride,
+                          const int32_t* row_first, const int32_t* q_per_frame, int n_frames, int M_total, int k_hi, int k_lo,
+                          int num_per_length, int32_t* out_assn, int32_t* out_len, int32_t* out_count, uint8_t* out_exact,
+                          int max_assn, int n_threads);
+
+/* ------------------------------------------------------------------------------------------ */
+/* exchange: the collectives of the sharded path on RCCL                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The reference issues no collective on this path (one process); with the memory sharded by instance range over the GPUs of a node
+ * two are needed: the all-gather of the per-shard candidate lists before the assignment search (north star) and the all-reduce(MIN)
+ * of per-point nearest distances for evaluate_transform against sharded clouds.  One communicator per process / GPU:
+ * ibl_comm_unique_id on rank 0 (returns the id size, 128 bytes), the id reaches the other ranks through the host's own channel,
+ * ibl_comm_init on every rank (current HIP device), then the collectives on the caller's stream.  The Python layer can use
+ * torch.distributed (the same RCCL) instead: ibloc_amd.parallel. */
+typedef struct ibl_comm ibl_comm;
+int ibl_comm_unique_id(void* out, int out_bytes);
+int ibl_comm_init(ibl_comm** out, int rank, int world, const void* unique_id, int id_bytes);
+int ibl_comm_destroy(ibl_comm* comm);
+/* recv [dev] world x bytes_per_rank: the contribution of rank r at offset r * bytes_per_rank */
+int ibl_allgather_topk(ibl_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+/* in place, element-wise minimum over the ranks of n floats (ibl_evaluate_points distances) */
+int ibl_allreduce_min(ibl_comm* comm, float* buf, int64_t n, void* stream);
+/* in place, element-wise maximum of n int32 (the "some rank needs the full rows" flag of a step) */
+int ibl_allreduce_max_i32(ibl_comm* comm, int32_t* buf, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* register: grids, normals + FPFH, feature matching, RANSAC, coloured ICP (rows a9-a13)        */
 /* ------------------------------------------------------------------------------------------ */
@@ -222,8 +280,8 @@ int ibl_reg_ctx_destroy(ibl_reg_ctx* ctx);
 /* drop every allocation of the arena, including memory grids built from it (they become invalid) */
 int ibl_reg_ctx_reset(ibl_reg_ctx* ctx);
 int64_t ibl_reg_ctx_high_water(const ibl_reg_ctx* ctx);
-/* device status word (bit 0: grid table overflow, bit 1: a k-NN query took the re-scan slow path);
- * synchronises the device */
+/* device status word (bit 0: grid table overflow, bit 1: a k-NN query took the re-scan slow path; bits 2-3 are internal to
+ * ibl_register_batch_cached); synchronises the device */
 int ibl_reg_ctx_status(ibl_reg_ctx* ctx, int clear);
 
 /* Clouds are passed as batches of segments: pts4 [dev] N x float4 (x, y, z, intensity =
@@ -304,16 +362,16 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
  *   normals4 [dev] N x float4, fpfh [dev] N x 33 with every row in MATCHING ORDER (bin 11 b + c at position
  *   3 * rank(c) + {b=1: 0, b=2: 1, b=0: 2}, rank over c = 5,4,6,3,7,2,8,1,9,0,10: the three histograms from their centre
  *   bins outwards, interleaved -- the order in which the feature search sums its squared differences, so that its
- *   early-abandon chain reads contiguously), fpfh_split / fpfh_norm [dev]: every row once more as bf16 hi + lo parts
- *   (x = hi + lo + r, |r| <= 2^-16 |x|) and its squared norm -- the operands of the matrix-core filter of the feature
- *   search (csrc/reg_featnn.hip), grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
+ *   early-abandon chain reads contiguously), fpfh_split / fpfh_norm [dev]: every row once more as 48 fp16 search operands
+ *   [x_0 .. x_32 | 8 8 | |x|^2 / 8 as hi + lo | 1e-3 |x|^2 rounded up | 0 ..] and its squared norm -- the operands of the
+ *   matrix-core filter of the feature search, whose one MFMA chain yields the whole distance bound (csrc/reg_featnn.hip), grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
  *   gradients are recomputed per job), bbox [HOST] n_seg x 6 = (min xyz, max xyz) -- all written by
  *   ibl_instance_features_batch (the call synchronises); voxel_size / grad_radius: the parameters they hold for
  *   (grad_radius = 2 * voxel_size * local_dist_factor in register_point_clouds). */
 typedef struct {
     const float* normals4;
     const float* fpfh;
-    const uint16_t* fpfh_split;   /* [dev] N x 96 bf16: terms 0..47 of the hi part | terms 0..47 of the lo part (33 real, 15 zero) */
+    const uint16_t* fpfh_split;   /* [dev] N x 48 fp16 search operands (layout above) */
     const float* fpfh_norm;       /* [dev] N: |row|^2 */
     const float* grad4;
     const float* bbox;

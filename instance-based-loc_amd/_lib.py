@@ -76,6 +76,12 @@ _SIGS = {
     "ibl_assign_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int]),
     "ibl_assign_candidates": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                         C.c_int, C.c_int]),
+    "ibl_comm_unique_id": (C.c_int, [vp, C.c_int]),
+    "ibl_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
+    "ibl_comm_destroy": (C.c_int, [vp]),
+    "ibl_allgather_topk": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "ibl_allreduce_min": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "ibl_allreduce_max_i32": (C.c_int, [vp, vp, C.c_int64, vp]),
     "ibl_topk_select": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "ibl_match_topk_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "ibl_match_topk": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp,

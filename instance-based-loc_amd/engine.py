@@ -108,7 +108,7 @@ class _Lane:
 
 
 class LocaliseEngine:
-    def __init__(self, memory: MemoryShard, encoder=None, assign_threads=0, k_hi=K_HI, k_lo=K_LO, group=None, rows_cap=224):
+    def __init__(self, memory: MemoryShard, encoder=None, assign_threads=0, k_hi=K_HI, k_lo=K_LO, group=None, rows_cap=224, comm=None):
         self.memory = memory
         self.encoder = encoder
         self.ctx = memory.ctx
@@ -119,7 +119,9 @@ class LocaliseEngine:
         self._pool_a = None             # stage-A worker of localise_stream
         self._pool_w = None             # lane threads of localise_concurrent
         self._lanes = []
-        self.exchange = ShardExchange(group, rows_cap) if memory.shard is not None and memory.shard[1] > 1 else None
+        # sharded memory: the stage-A collectives go through torch.distributed's group, or through the library's RCCL communicator
+        # (parallel.RcclComm) when one is given; a one-rank `comm` exercises the exchange path on a single GPU
+        self.exchange = ShardExchange(group, rows_cap, comm) if memory.shard is not None and (memory.shard[1] > 1 or comm is not None) else None
         self.stats = {"frames": 0, "fallback_frames": 0}        # how often the candidate search had to be redone on full rows
 
     def close(self):

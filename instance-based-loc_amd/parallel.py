@@ -56,15 +56,87 @@ def merge_lists_host(val: np.ndarray, idx: np.ndarray, cnt: np.ndarray):
     return np.take_along_axis(v, order, 1), np.take_along_axis(j, order, 1), n.sum(axis=0).astype(np.int32)
 
 
+class RcclComm:
+    """The library's own RCCL communicator (include/ibloc.h `ibl_comm_*`): the collectives of the sharded path without going through
+    torch.distributed's process group.  The unique id is created on rank 0 and broadcast with torch.distributed (any host channel
+    would do); every rank then calls ncclCommInitRank on its current device.  `ShardExchange(comm=RcclComm(...))` uses it."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_ubyte * 256)()
+        n = 128
+        if self.rank == 0:
+            n = _lib.lib.ibl_comm_unique_id(buf, 256)
+            if n < 0:
+                _lib.check(n, "ibl_comm_unique_id")
+        ids = [bytes(buf[:n])] if self.rank == 0 else [None]
+        dist.broadcast_object_list(ids, src=0, group=group)
+        raw = (C.c_ubyte * len(ids[0])).from_buffer_copy(ids[0])
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib.ibl_comm_init(C.byref(self._h), self.rank, self.world, raw, len(ids[0])), "ibl_comm_init")
+
+    @staticmethod
+    def single():
+        """a one-rank communicator (no process group needed): what a single-GPU process gets"""
+        self = RcclComm.__new__(RcclComm)
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C, self.rank, self.world = _lib, C, 0, 1
+        buf = (C.c_ubyte * 256)()
+        n = _lib.lib.ibl_comm_unique_id(buf, 256)
+        if n < 0:
+            _lib.check(n, "ibl_comm_unique_id")
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib.ibl_comm_init(C.byref(self._h), 0, 1, buf, n), "ibl_comm_init")
+        return self
+
+    def close(self):
+        if self._h:
+            self._lib.lib.ibl_comm_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather(self, out: torch.Tensor, mine: torch.Tensor):
+        assert out.is_contiguous() and mine.is_contiguous() and out.numel() * out.element_size() == self.world * mine.numel() * mine.element_size()
+        self._lib.check(self._lib.lib.ibl_allgather_topk(self._h, mine.data_ptr(), out.data_ptr(), mine.numel() * mine.element_size(),
+                                                         torch.cuda.current_stream().cuda_stream), "ibl_allgather_topk")
+
+    def all_reduce_min(self, buf: torch.Tensor):
+        assert buf.dtype == torch.float32 and buf.is_contiguous()
+        self._lib.check(self._lib.lib.ibl_allreduce_min(self._h, buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream),
+                        "ibl_allreduce_min")
+
+    def all_reduce_max_i32(self, buf: torch.Tensor):
+        assert buf.dtype == torch.int32 and buf.is_contiguous()
+        self._lib.check(self._lib.lib.ibl_allreduce_max_i32(self._h, buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream),
+                        "ibl_allreduce_max_i32")
+
+
 class ShardExchange:
     """The collectives of one rank's stage A when the embedding memory is sharded over `group`.  rows_cap: fixed number of query
-    rows every rank contributes per step (shorter batches are zero-padded), so that no size has to be negotiated."""
+    rows every rank contributes per step (shorter batches are zero-padded), so that no size has to be negotiated.  comm: an
+    `RcclComm` (the library's communicator) instead of torch.distributed's process group -- the same collectives either way."""
 
-    def __init__(self, group=None, rows_cap: int = 224):
+    def __init__(self, group=None, rows_cap: int = 224, comm: "RcclComm" = None):
         self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.comm = comm
+        self.world = comm.world if comm is not None else dist.get_world_size(group)
+        self.rank = comm.rank if comm is not None else dist.get_rank(group)
         self.cap = int(rows_cap)
+
+    def _all_gather(self, out, mine):
+        if self.comm is not None:
+            self.comm.all_gather(out, mine)
+        else:
+            dist.all_gather_into_tensor(out, mine, group=self.group)
 
     def gather_queries(self, detn: torch.Tensor) -> torch.Tensor:
         """(R, D) normalised query rows of this rank -> (W * cap, D): rank r's rows at [r * cap, r * cap + R_r), zeros after."""
@@ -74,7 +146,7 @@ class ShardExchange:
         mine = torch.zeros((self.cap, D), dtype=detn.dtype, device=detn.device)
         mine[:R] = detn
         out = torch.empty((self.world * self.cap, D), dtype=detn.dtype, device=detn.device)
-        dist.all_gather_into_tensor(out, mine, group=self.group)
+        self._all_gather(out, mine)
         return out
 
     def gather_candidates(self, val: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor):
@@ -82,13 +154,16 @@ class ShardExchange:
         S = val.shape[1]
         mine = pack_candidates(val, idx, cnt)                             # (W * cap, P)
         out = torch.empty((self.world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(out, mine, group=self.group)          # (concatenated form: the one gloo implements too)
+        self._all_gather(out, mine)                                        # (concatenated form: the one gloo implements too)
         own = out.view(self.world, mine.shape[0], mine.shape[1])[:, self.rank * self.cap:(self.rank + 1) * self.cap]     # (W, cap, P)
         return unpack_candidates(own, S)
 
     def any_flag(self, flag: bool, device) -> bool:
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if self.comm is not None:
+            self.comm.all_reduce_max_i32(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return bool(t.item())
 
     def gather_blocks(self, aug_local: torch.Tensor, n_inst: int) -> torch.Tensor:
@@ -99,7 +174,7 @@ class ShardExchange:
         mine = torch.zeros((aug_local.shape[0], wmax), dtype=aug_local.dtype, device=aug_local.device)
         mine[:, :aug_local.shape[1] - 1] = aug_local[:, :-1]
         out = torch.empty((self.world * mine.shape[0], wmax), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(out, mine, group=self.group)
+        self._all_gather(out, mine)
         own = out.view(self.world, mine.shape[0], wmax)[:, self.rank * self.cap:(self.rank + 1) * self.cap]
         full = torch.cat([own[r, :, :w] for r, w in enumerate(widths)] +
                          [torch.ones((self.cap, 1), dtype=aug_local.dtype, device=aug_local.device)], dim=1)
@@ -155,11 +230,13 @@ def fitness_rmse_from_d2(d2: torch.Tensor, job_sizes):
     return np.array(fit), np.array(rmse)
 
 
-def evaluate_sharded(local_d2: torch.Tensor, job_sizes, group=None):
+def evaluate_sharded(local_d2: torch.Tensor, job_sizes, group=None, comm: "RcclComm" = None):
     """Whole-memory evaluation with the memory clouds sharded by instance range: `local_d2` = this rank's
     `registration.evaluate_points` output against the points it owns; the nearest memory point overall is the minimum over the ranks
     (all-reduce MIN over RCCL / gloo: 4 bytes per transformed detected point and candidate), then fitness / rmse as on one GPU."""
     d2 = local_d2.clone()
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if comm is not None:
+        comm.all_reduce_min(d2)
+    elif dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(d2, op=dist.ReduceOp.MIN, group=group)
     return fitness_rmse_from_d2(d2, job_sizes)

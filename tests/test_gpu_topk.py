@@ -102,3 +102,33 @@ def test_engine_on_candidates_equals_engine_on_full_rows(M, dup):
     elif M > 224:
         assert eng.stats["fallback_frames"] == 0, eng.stats
     ctx.close()
+
+
+def test_sharded_exchange_through_the_library_rccl_communicator_world_1():
+    """the collectives of the sharded stage A (include/ibloc.h ibl_comm_* / ibl_allgather_topk / ibl_allreduce_*) on a one-rank RCCL
+    communicator: the engine takes the exchange path (query gather, candidate gather, flag all-reduce) and must return the lists of
+    the un-sharded engine; the all-reduce(MIN) of the sharded evaluation is the identity"""
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard
+    from ibloc_amd.parallel import RcclComm, evaluate_sharded
+    from ibloc_amd.registration import RegContext
+    comm = RcclComm.single()
+    rng = np.random.default_rng(3)
+    M, E, D, F = 2000, 2, 64, 10
+    base = rng.normal(size=(M, D))
+    emb = (base[:, None, :] + rng.normal(0, 0.2, size=(M, E, D))).astype(np.float32)
+    q = rng.integers(1, 8, size=F)
+    ids = rng.integers(0, M, size=int(q.sum()))
+    det = (base[ids] + rng.normal(0, 0.15, size=(len(ids), D))).astype(np.float32)
+    ctx = RegContext(64 << 20)
+    plain = LocaliseEngine(MemoryShard(ctx, list(emb))).localise_batch(None, q, det_emb=det, register=False)
+    eng = LocaliseEngine(MemoryShard(ctx, list(emb), shard=(0, 1)), comm=comm, rows_cap=80)
+    assert eng.exchange is not None
+    got = eng.localise_batch(None, q, det_emb=det, register=False)
+    assert [r.assignments for r in got] == [r.assignments for r in plain]
+    piped = list(eng.localise_stream([dict(det=None, q_per_frame=q, det_emb=det)] * 3, register=False))
+    assert all([r.assignments for r in p] == [r.assignments for r in plain] for p in piped)
+    d2 = torch.tensor([0.1, float("inf"), 0.3, 0.2], device="cuda")
+    fit, rmse = evaluate_sharded(d2, [2, 2], comm=comm)
+    assert np.allclose(fit, [0.5, 1.0]) and np.allclose(rmse, [np.sqrt(0.1), np.sqrt(0.25)])
+    comm.close()
+    ctx.close()
