@@ -38,7 +38,8 @@ struct WaveLds {
     unsigned b_bits[KNN_CAPB];
     int b_idx[KNN_CAPB];
     int b_j[KNN_CAPB];
-    int scratch[64];
+    int scratch[64];         // [0, 33) SPFH histogram, [62, 64) key range of the index sort
+    int rank_pre[64];        // index sort: packed per-word bitmap prefixes
     int sel_j[256];          // consumers that do heavy per-neighbour work first compact the selected set here
     float sel_d2[256];
 };
@@ -441,20 +442,60 @@ __device__ inline void fast_eigen_normal_d(const double* cov, double* n) {
 template <bool WITH_D2, class Acc>
 __device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const Acc& acc, int k) {
     const int lane = threadIdx.x & 63;
+    if (lane == 0) { L->scratch[62] = 0x7FFFFFFF; L->scratch[63] = -1; }
     wave_lds_sync();
 #ifdef KNN_LAB_NO_SORT
     for (int t = lane; t < k; t += 64) { L->b_j[t] = L->sel_j[t]; if (WITH_D2) L->b_bits[t] = __float_as_uint(L->sel_d2[t]); }
     wave_lds_sync();
     return;
 #endif
-    for (int t = lane; t < k; t += 64) L->b_idx[t] = acc.ord(L->sel_j[t]);
-    wave_lds_sync();
     for (int t = lane; t < k; t += 64) {
-        const int key = L->b_idx[t];
-        int r = 0;
-        for (int u = 0; u < k; ++u) r += L->b_idx[u] < key ? 1 : 0;
-        L->b_j[r] = L->sel_j[t];
-        if (WITH_D2) L->b_bits[r] = __float_as_uint(L->sel_d2[t]);
+        const int key = acc.ord(L->sel_j[t]);
+        L->b_idx[t] = key;
+        atomicMin(&L->scratch[62], key);
+        atomicMax(&L->scratch[63], key);
+    }
+    wave_lds_sync();
+    const int kmin = L->scratch[62];
+    const unsigned span = (unsigned)(L->scratch[63] - kmin);
+    if (span < 32u * KNN_BINS) {
+        // the keys are distinct original indices: rank = number of set bits below the key's bit in a bitmap of the span
+        // (L->hist is free once the selection is over); per-word exclusive prefixes fit a byte (rank < k <= 256)
+        unsigned* bits = reinterpret_cast<unsigned*>(L->hist);
+        *reinterpret_cast<uint4*>(&bits[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_sync();
+        for (int t = lane; t < k; t += 64) {
+            const unsigned o = (unsigned)(L->b_idx[t] - kmin);
+            atomicOr(&bits[o >> 5], 1u << (o & 31u));
+        }
+        wave_lds_sync();
+        const uint4 w = *reinterpret_cast<const uint4*>(&bits[4 * lane]);
+        const int c0 = __popc(w.x), c1 = __popc(w.y), c2 = __popc(w.z), c3 = __popc(w.w);
+        const int s = c0 + c1 + c2 + c3;
+        int incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        const unsigned e0 = (unsigned)(incl - s), e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
+        reinterpret_cast<unsigned*>(L->rank_pre)[lane] = (e0 & 255u) | ((e1 & 255u) << 8) | ((e2 & 255u) << 16) | ((e3 & 255u) << 24);
+        wave_lds_sync();
+        const unsigned char* pre = reinterpret_cast<const unsigned char*>(L->rank_pre);
+        for (int t = lane; t < k; t += 64) {
+            const unsigned o = (unsigned)(L->b_idx[t] - kmin);
+            const int r = (int)pre[o >> 5] + __popc(bits[o >> 5] & ((1u << (o & 31u)) - 1u));
+            L->b_j[r] = L->sel_j[t];
+            if (WITH_D2) L->b_bits[r] = __float_as_uint(L->sel_d2[t]);
+        }
+    } else {
+        for (int t = lane; t < k; t += 64) {
+            const int key = L->b_idx[t];
+            int r = 0;
+            for (int u = 0; u < k; ++u) r += L->b_idx[u] < key ? 1 : 0;
+            L->b_j[r] = L->sel_j[t];
+            if (WITH_D2) L->b_bits[r] = __float_as_uint(L->sel_d2[t]);
+        }
     }
     wave_lds_sync();
 }

@@ -13,5 +13,5 @@ while [ $# -gt 0 ]; do
   objs=$(echo $objs | sed "s/\b${f%.*}\.o\b//")
   objs="$objs ../../tools/_lab/${f%.*}_$tag.o"
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_lab/libibloc_$tag.so $objs -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_lab/libibloc_$tag.so $objs -lpthread -L/opt/rocm/lib -lrccl
 echo built tools/_lab/libibloc_$tag.so
