@@ -1005,7 +1005,18 @@ struct FpfhTile {
     unsigned char cnt[64][36];
     double inc[64];       // 100 / (k_j - 1), or 0 when the neighbour has no SPFH
     double dist[64];      // d2; <= 0 marks a skipped entry (self or zero distance)
+    double rcp[64];       // RN(1 / d2), one IEEE division per neighbour instead of one per (neighbour, bin)
 };
+
+// RN(x / d) from y = RN(1 / d): q <- q + (x - q d) y twice (Markstein 1990: with a correctly rounded reciprocal and a
+// faithful q the correction yields the correctly rounded quotient; the first step makes q faithful, the second applies the
+// theorem).  d is a float's square distance (24 significant bits), so the theorem's all-ones-mantissa exception cannot occur;
+// x and d are far from the under/overflow ranges.  5 fp64 operations instead of the ~12 of the division expansion.
+__device__ __forceinline__ double div_by_rcp(double x, double d, double y) {
+    const double q0 = x * y;
+    const double q1 = fma(fma(-q0, d, x), y, q0);
+    return fma(fma(-q1, d, x), y, q1);
+}
 
 __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __restrict__ spfh_cnt, const int* __restrict__ nbr_idx,
                                                        const float* __restrict__ nbr_d2, const int* __restrict__ nbr_cnt, int K, int n,
@@ -1030,7 +1041,9 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
 #pragma unroll
                 for (int w = 0; w < 9; ++w) dst[w] = src[w];
                 T.inc[lane] = kj > 1 ? 100.0 / (double)(kj - 1) : 0.0;
-                T.dist[lane] = (j == qi || dist == 0.0) ? -1.0 : dist;
+                const bool skip = j == qi || dist == 0.0;
+                T.dist[lane] = skip ? -1.0 : dist;
+                T.rcp[lane] = skip ? 0.0 : 1.0 / dist;
             }
             wave_lds_sync();
             const int m = min(64, k - t0);
@@ -1040,7 +1053,7 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
                 const unsigned cb = T.cnt[r][b];
                 if (cb == 0) continue;                        // an empty bin adds an exact zero
                 const float sp = (float)((double)cb * T.inc[r]);
-                acc += (double)sp / dist;
+                acc += div_by_rcp((double)sp, dist, T.rcp[r]);
             }
             wave_lds_sync();
         }
