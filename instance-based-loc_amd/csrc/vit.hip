@@ -9,7 +9,7 @@
 // QKV, attention output and MLP hidden as fp16 (11-bit significand: rel-L2 1.2e-3 on the 12-layer ViT-B/14 where bf16 operands gave 1.1e-2, same MFMA rate); weights fp16 [N][K] (K contiguous, i.e. the
 // nn.Linear layout) so that both MFMA operands are 16-byte K-contiguous fragments.
 //
-// Kernels: gemm_f16_tn (128x128x64 LDS-tiled, register-staged double buffer, fused epilogues:
+// Kernels: gemm_f16_tn (256x256x64 / 128x128x64 LDS tiles filled by direct-to-LDS buffer loads, software-pipelined K loop, fused epilogues:
 // bias / bias+GELU / bias*layerscale+residual / patch-embed scatter+pos-embed), layernorm (one
 // wave per row), attention (one workgroup per (crop, head), K and V^T of the head staged in LDS,
 // S^T = K Q^T so that the softmaxed probabilities are already the A operand of P V), CLS/final
@@ -71,8 +71,8 @@ template <int BK> __device__ __forceinline__ int keyx_pair(int r) { return BK ==
 // The MFMA computes the TRANSPOSED tile (W is the A operand, the activations the B operand) and MFMA row 4*fg + r of
 // n-tile j is mapped to weight row 16*fg + 4*j + r, so that every lane ends up with 16 CONSECUTIVE output columns of one
 // output row: the epilogue is 16-byte vector stores.  Operand tiles are staged with direct-to-LDS loads
-// (global_load_lds_dwordx4): one wave instruction writes 1 KiB = 8 tile rows linearly, so the XOR swizzle is applied
-// to the per-lane SOURCE address.
+// (buffer_load_dwordx4 ... offen lds): one wave instruction writes 1 KiB = 8 tile rows linearly, so the XOR swizzle is applied
+// to the per-lane SOURCE offset.
 // Exact-form GELU, 0.5 v (1 + erf(v / sqrt 2)), with erfc from Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7 in erf, two orders
 // below the fp16 rounding of the stored activation).  libm's erff costs ~35 VALU instructions per element, which made the
 // fc1 epilogue as long as its K loop; this form is 14.
@@ -85,6 +85,32 @@ __device__ __forceinline__ float gelu_erf(float v) {
     p = fmaf(p, t, 0.254829592f);
     const float c = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erfc(z)
     return 0.5f * v * (v < 0.f ? c : 2.0f - c);
+}
+
+// Two elements at a time on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes of arithmetic per
+// instruction).  Same erfc polynomial; the sign select is folded away with |v| = sqrt(2) z:
+//   0.5 v (1 + erf(v / sqrt 2)) = 0.5 v + 0.5 |v| (1 - erfc(z)) = 0.5 v + (z / sqrt 2) (1 - erfc(z))
+// (for v << 0 the two terms cancel to an absolute error of ~|v| 6e-8, three orders below the fp16 rounding of the row's other
+// activations).  13 packed + 3 scalar operations per pair against 19 scalar per element: the fc1 epilogue was VALU-bound.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    f32x2 z;
+    z.x = fabsf(v.x) * 0.70710678118654752f;
+    z.y = fabsf(v.y) * 0.70710678118654752f;
+    const f32x2 d = z * 0.3275911f + 1.0f;
+    f32x2 t;
+    t.x = __builtin_amdgcn_rcpf(d.x);
+    t.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2 p = t * 1.061405429f + -1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t + -0.284496736f;
+    p = p * t + 0.254829592f;
+    const f32x2 a = (z * -1.4426950408889634f) * z;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(a.x);
+    e.y = __builtin_amdgcn_exp2f(a.y);
+    const f32x2 u = 1.0f - (p * t) * e;                       // erf(z)
+    return (z * u) * 0.70710678118654752f + v * 0.5f;
 }
 
 #ifdef IBL_GEMM_STAMPS     // lab builds only (tools/perf_gemm.py --stamps): per-block phase clocks
@@ -103,9 +129,10 @@ extern "C" int ibl_gemm_stamps_read(long long* dst, int n) {
 #define GEMM_STAMP(k)
 #endif
 
-template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS>
+template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
                                                                   int64_t ldw, int M, int N, int K, GemmEpi epi) {
+#if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type and builtins exist in the device pass only
     constexpr int BM = WM * MI * 16, BN = WN * 64, NW = WM * WN;
     constexpr int LDS_ROW = BK * 2;          // bytes per tile row, XOR-swizzled 16-byte chunks (no padding)
     constexpr int CPR = BK / 8, RPI = 64 / CPR;             // chunks per row; rows per 1 KiB wave instruction
@@ -125,52 +152,174 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     // columns (one 16-byte store) of n-tile pair j / 2 and the four lane groups cover 64 contiguous bytes of the row
     constexpr bool PAIR = EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16;
 #define KEYW(r) (NAT ? keyx_act<BK>(r) : (PAIR ? keyx_pair<BK>(r) : keyx_w<BK>(r)))
-    // XCD-aware remap: consecutive tiles along N (sharing the A panel) stay on one XCD's L2
     const int nbn = N / BN;
     const int nbm = (M + BM - 1) / BM;
     const int nwg = nbn * nbm;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
-    const int bm = bid / nbn, bn = bid % nbn;
-    const int row0 = bm * BM, col0 = bn * BN;
-
-    const u16* a_src[GA];
-    const u16* w_src[GW];
-#pragma unroll
-    for (int i = 0; i < GA; ++i) {
-        const int r = (wave + NW * i) * RPI + lane / CPR, pch = lane % CPR;
-        int ar = row0 + r;
-        if (ar >= M) ar = M - 1;
-        a_src[i] = A + (int64_t)ar * lda + ((pch ^ keyx_act<BK>(r)) << 3);
-    }
-#pragma unroll
-    for (int i = 0; i < GW; ++i) {
-        const int r = (wave + NW * i) * RPI + lane / CPR, pch = lane % CPR;
-        w_src[i] = W + (int64_t)(col0 + r) * ldw + ((pch ^ KEYW(r)) << 3);
-    }
+    // source of piece i: a buffer resource on the tile's first row (SGPRs) + a per-lane 32-bit byte offset + the K offset (SGPR):
+    // buffer_load_dwordx4 ... offen lds needs no 64-bit address pair per piece (16 VGPRs with global_load_lds)
+    __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
+    unsigned a_off[GA], w_off[GW];
+    int row0, col0;
+    // tile t of the launch -> (row0, col0) and this wave's source addresses.  XCD-aware remap: consecutive tiles along N (sharing
+    // the A panel) stay on one XCD's L2 (t % 8 labels the XCD for the one-shot grid and for the persistent one, whose stride is a
+    // multiple of 8)
+#define GEMM_SET_TILE(t)                                                                           \
+    do {                                                                                           \
+        int _bid = (t);                                                                            \
+        {                                                                                          \
+            const int _q = nwg / 8, _r = nwg % 8, _xcd = _bid % 8;                                 \
+            _bid = (_xcd < _r ? _xcd * (_q + 1) : _r * (_q + 1) + (_xcd - _r) * _q) + _bid / 8;    \
+        }                                                                                          \
+        row0 = (_bid / nbn) * BM;                                                                  \
+        col0 = (_bid % nbn) * BN;                                                                  \
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)row0 * lda), 0, -1, 0x00020000); \
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)col0 * ldw), 0, -1, 0x00020000); \
+        _Pragma("unroll") for (int _i = 0; _i < GA; ++_i) {                                        \
+            const int _rr = (wave + NW * _i) * RPI + lane / CPR, _pch = lane % CPR;                \
+            int _ar = _rr;                                                                         \
+            if (row0 + _ar >= M) _ar = M - 1 - row0;                                               \
+            a_off[_i] = (unsigned)(((int64_t)_ar * lda + ((_pch ^ keyx_act<BK>(_rr)) << 3)) * 2);  \
+        }                                                                                          \
+        _Pragma("unroll") for (int _i = 0; _i < GW; ++_i) {                                        \
+            const int _rr = (wave + NW * _i) * RPI + lane / CPR, _pch = lane % CPR;                \
+            w_off[_i] = (unsigned)(((int64_t)_rr * ldw + ((_pch ^ KEYW(_rr)) << 3)) * 2);          \
+        }                                                                                          \
+    } while (0)
+    int tile = blockIdx.x;
+    GEMM_SET_TILE(tile);
 #define GEMM_GLDS(buf, kt)                                                                                              \
     do {                                                                                                                \
         const int64_t _ko = (int64_t)(kt) * BK;                                                                         \
         _Pragma("unroll") for (int _i = 0; _i < GA; ++_i)                                                               \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[_i] + _ko),         \
-                                             (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE + (wave + NW * _i) * 1024), 16, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE + (wave + NW * _i) * 1024), \
+                                                     16, a_off[_i], (unsigned)(_ko * 2), 0, 0);                          \
         _Pragma("unroll") for (int _i = 0; _i < GW; ++_i)                                                               \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[_i] + _ko),         \
-                                             (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE + A_BYTES + (wave + NW * _i) * 1024), 16, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(smem + (buf) * STAGE + A_BYTES + (wave + NW * _i) * 1024), \
+                                                     16, w_off[_i], (unsigned)(_ko * 2), 0, 0);                          \
     } while (0)
 
     f32x4 acc[MI][4];      // [m-tile i][n-tile j]
+    const int nk = K / BK;
+    GEMM_STAMP(0);
+    constexpr int NP = GA + GW;
+    const int fr = lane & 15, fg = lane >> 4;
+    int arow[MI], wrow[4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) arow[i] = wm * (MI * 16) + i * 16 + fr;              // activation row (B operand column)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)                   // weight row of MFMA row fr in n-tile j
+        wrow[j] = NAT ? wn * 64 + 16 * j + fr
+                      : (PAIR ? wn * 64 + 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3) : wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3));
+#define GEMM_PIECE(stage, pc)                                                                                                       \
+    do {                                                                                                                            \
+        const int64_t _ko = (int64_t)(stage) * BK;                                                                                  \
+        unsigned char* _dst = smem + ((stage) & 1) * STAGE;                                                                         \
+        if ((pc) < GA)                                                                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(_dst + (wave + NW * (pc)) * 1024), 16,   \
+                                                     a_off[(pc) < GA ? (pc) : 0], (unsigned)(_ko * 2), 0, 0);                               \
+        else                                                                                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(_dst + A_BYTES + (wave + NW * ((pc) - GA)) * 1024), \
+                                                     16, w_off[(pc) >= GA ? (pc) - GA : 0], (unsigned)(_ko * 2), 0, 0);                     \
+    } while (0)
+#define FRAG_W(buf, ks, j) (*reinterpret_cast<const h16x8*>(smem + (buf) * STAGE + A_BYTES + wrow[j] * LDS_ROW + (((4 * (ks) + fg) ^ KEYW(wrow[j])) << 4)))
+#define FRAG_A(buf, ks, i) (*reinterpret_cast<const h16x8*>(smem + (buf) * STAGE + arow[i] * LDS_ROW + (((4 * (ks) + fg) ^ keyx_act<BK>(arow[i])) << 4)))
+    // The pipelined form is launched as a persistent grid (one workgroup per CU walks the tiles t, t + grid, ...): the next tile's
+    // first stage is requested before the epilogue of the current one, so its latency hides under the stores.
+    static_assert(!PIPE || (BK == 64 && NS == 2 && MI % 2 == 0), "pipelined loop: BK 64, two stages");
+#ifndef IBL_GEMM_HA_DIV
+#define IBL_GEMM_HA_DIV 4
+#endif
+    constexpr int HA = MI / IBL_GEMM_HA_DIV, N2B = MI - HA;       // groups before / after the barrier in the second K half
+    constexpr int NL = MI + 4;                                    // fragment reads per K half
+    constexpr int LB = (NL + MI - 2) / (MI - 1);                  // set-B reads per phase-1 group (none after the last group)
+    constexpr int LA = (NL + N2B - 2) / (N2B - 1);                // set-A reads per phase-2b group (none before the last group)
+    constexpr int NSLOT = N2B + MI;
+    static_assert(!PIPE || NP <= 2 * NSLOT, "pieces per stage exceed the slots of a step");
+    bool first_tile = true;
+    for (;;) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BK;
-    GEMM_STAMP(0);
-    constexpr int NP = GA + GW;
+    if constexpr (PIPE) {
+        // Software-pipelined K loop (BK = 64, two LDS stages, two fragment register sets).  One K step of a wave:
+        //   phase 1   MI groups of 4 MFMAs on the step's first K half (set A), the reads of its second half (set B) between them
+        //   phase 2a  MI / 2 groups on set B
+        //   wait for this wave's pieces of the NEXT stage, workgroup barrier
+        //   phase 2b  MI / 2 groups on set B, the reads of the next stage's first half (set A) between them
+        // so that no MFMA waits on an LDS read issued just before it (the compiler's own schedule of the plain loop read each
+        // fragment pair right before its use: five exposed LDS round trips per step, in all eight waves at once).  The direct-to-LDS
+        // pieces of stage s + 2 overwrite the buffer of stage s: the first half of them is issued in phase 2b of step s (every wave has
+        // passed the barrier, so every wave's reads of that buffer have returned), the rest in phase 1 of step s + 1; they have a
+        // whole step to land before the wait that precedes the barrier of step s + 1.
+        // Piece slots: one after each MFMA group of phase 2b (stage kt + 2) and of phase 1 (stage kt + 1, i.e. the same stage one step
+        // later); slot u carries piece u, the pieces beyond the slot count ride on the first slots.  (Giving the two waves of a SIMD
+        // alternate slots, so that one issues MFMAs while the other waits on its piece, measured 4 % slower.)
+#define GEMM_SLOT(u, stage)                                                                        \
+    do {                                                                                           \
+        if ((u) < NP) GEMM_PIECE(stage, (u) < NP ? (u) : 0);                                       \
+        if (NSLOT + (u) < NP) GEMM_PIECE(stage, NSLOT + (u) < NP ? NSLOT + (u) : 0);               \
+    } while (0)
+#define GEMM_PROLOGUE()                                                                            \
+    do {                                                                                           \
+        _Pragma("unroll") for (int _pc = 0; _pc < NP; ++_pc) GEMM_PIECE(0, _pc);                   \
+        if (nk > 1) {                                   /* the phase-2b slots of a step before the first */ \
+            _Pragma("unroll") for (int _g = 0; _g < N2B; ++_g) GEMM_SLOT(_g, 1);                   \
+        }                                                                                          \
+    } while (0)
+        if (first_tile) GEMM_PROLOGUE();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GEMM_STAMP(1);
+        h16x8 afA[MI], wfA[4], afB[MI], wfB[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wfA[j] = FRAG_W(0, 0, j);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) afA[i] = FRAG_A(0, 0, i);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+            // ---- phase 1: read t of a K half is weight fragment t / 2 (t even, t < 8) or the next activation fragment
+#pragma unroll
+            for (int g = 0; g < MI; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfA[j], afA[g], acc[g][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);         // reads after the group: the wait before it then covers set A only
+#pragma unroll
+                for (int t = g * LB; t < (g + 1) * LB && t < NL; ++t) {
+                    if (t < 8 && (t & 1) == 0) wfB[t / 2] = FRAG_W(buf, 1, t / 2);
+                    else afB[t < 8 ? t / 2 : t - 4] = FRAG_A(buf, 1, t < 8 ? t / 2 : t - 4);
+                }
+                if (more1) GEMM_SLOT(N2B + g, kt + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- phase 2a
+#pragma unroll
+            for (int g = 0; g < HA; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfB[j], afB[g], acc[g][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces have landed, its set-B reads have returned
+            __syncthreads();
+            // ---- phase 2b
+            const int nb = buf ^ 1;
+#pragma unroll
+            for (int g = 0; g < N2B; ++g) {
+                if (more1) {
+#pragma unroll
+                    for (int t = g * LA; t < (g + 1) * LA && t < NL; ++t) {
+                        if (t < 8 && (t & 1) == 0) wfA[t / 2] = FRAG_W(nb, 0, t / 2);
+                        else afA[t < 8 ? t / 2 : t - 4] = FRAG_A(nb, 0, t < 8 ? t / 2 : t - 4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[HA + g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfB[j], afB[HA + g], acc[HA + g][j], 0, 0, 0);
+                if (more2) GEMM_SLOT(g, kt + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
     // NS LDS stages: the loads of K steps 0 .. NS - 2 are in flight before the loop, step kt issues those of step kt + NS - 1, and the
     // wait that closes a step lets the (NS - 2) youngest stages stay in flight (vmcnt counts LDS-DMA pieces in issue order)
 #pragma unroll
@@ -180,14 +329,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * NP) : "memory");
     __syncthreads();
     GEMM_STAMP(1);
-    const int fr = lane & 15, fg = lane >> 4;
-    int arow[MI], wrow[4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) arow[i] = wm * (MI * 16) + i * 16 + fr;              // activation row (B operand column)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)                   // weight row of MFMA row fr in n-tile j
-        wrow[j] = NAT ? wn * 64 + 16 * j + fr
-                      : (PAIR ? wn * 64 + 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3) : wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3));
     // One K step = 2 * MI groups of 4 MFMAs.  The GA + GW direct-to-LDS pieces of the NEXT tile are issued one at a time
     // between those groups: a piece blocks its wave's issue port for ~100 cycles, and eight of them back to back at the top
     // of the step (right after the barrier, in every wave at once) left the MFMA pipe idle for a third of the step.
@@ -223,11 +364,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
                 for (int pc = (g < NGI ? g * NP / NGI : NP); pc < (g < NGI ? (g + 1) * NP / NGI : NP); ++pc) {
                     if (more) {
                         if (pc < GA)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[pc] + ko),
-                                                             (__attribute__((address_space(3))) void*)(nxt + (wave + NW * pc) * 1024), 16, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(nxt + (wave + NW * pc) * 1024), 16,
+                                                                     a_off[pc], (unsigned)(ko * 2), 0, 0);
                         else
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[pc - GA] + ko),
-                                                             (__attribute__((address_space(3))) void*)(nxt + A_BYTES + (wave + NW * (pc - GA)) * 1024), 16, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(nxt + A_BYTES + (wave + NW * (pc - GA)) * 1024), 16,
+                                                                     w_off[pc - GA], (unsigned)(ko * 2), 0, 0);
                     }
                 }
             }
@@ -244,13 +385,25 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         }
         __syncthreads();
     }
-#undef GEMM_GLDS
+    }
     GEMM_STAMP(2);
+    // the tile this block computes next: its first stage is requested now (both LDS buffers are free: every wave's last LDS read
+    // returned before the barrier of the final K step)
+    const int erow0 = row0, ecol0 = col0;
+    tile += gridDim.x;
+    const bool has_next = PIPE && tile < nwg;
+    if constexpr (PIPE) {
+        if (has_next) {
+            GEMM_SET_TILE(tile);
+            GEMM_PROLOGUE();
+        }
+    }
+
 
     // epilogue.  D layout: col = lane & 15 -> output row m; MFMA row 4*fg + r of n-tile j -> output column 16*fg + 4*j + r
     if (NAT) {
         // x[row][n] += scale[n] * (acc + bias[n]); lane (fr, fg) owns columns 16 j + 4 fg + 0..3 of n-tile j
-        const int nb = col0 + wn * 64 + 4 * fg;
+        const int nb = ecol0 + wn * 64 + 4 * fg;
         float4 b4[4], s4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -259,7 +412,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int row = row0 + wm * (MI * 16) + i * 16 + fr;
+            const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
             if (row >= M) continue;
             float* orow = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + nb;
 #pragma unroll
@@ -276,10 +429,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         __syncthreads();
         GEMM_STAMP(3);
 #endif
-        return;
-    }
-    if (PAIR) {
-        const int nb = col0 + wn * 64 + 8 * fg;
+    } else if (PAIR) {
+        const int nb = ecol0 + wn * 64 + 8 * fg;
         float bb[2][8];
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2)
@@ -290,16 +441,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
             }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int row = row0 + wm * (MI * 16) + i * 16 + fr;
+            const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
             if (row >= M) continue;
             u16* orow = reinterpret_cast<u16*>(epi.out) + (int64_t)row * epi.ldo + nb;
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {
                 float v[8];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    v[t] = acc[i][2 * j2 + (t >> 2)][t & 3] + bb[j2][t];
-                    if (EPI == EPI_BIAS_GELU_H16) v[t] = gelu_erf(v[t]);
+                for (int t = 0; t < 8; t += 2) {
+                    f32x2 x = {acc[i][2 * j2 + (t >> 2)][t & 3], acc[i][2 * j2 + (t >> 2)][(t & 3) + 1]};
+                    x += f32x2{bb[j2][t], bb[j2][t + 1]};
+                    if (EPI == EPI_BIAS_GELU_H16) x = gelu_erf2(x);
+                    v[t] = x.x; v[t + 1] = x.y;
                 }
                 *reinterpret_cast<uint4*>(orow + 32 * j2) =
                     make_uint4((unsigned)f2h(v[0]) | ((unsigned)f2h(v[1]) << 16), (unsigned)f2h(v[2]) | ((unsigned)f2h(v[3]) << 16),
@@ -311,9 +464,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         __syncthreads();
         GEMM_STAMP(3);
 #endif
-        return;
-    }
-    const int n0 = col0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
+    } else {
+    const int n0 = ecol0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
     float bias[16], scale[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -325,7 +477,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int row = row0 + wm * (MI * 16) + i * 16 + fr;
+        const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
         if (row >= M) continue;
         float v[16];
 #pragma unroll
@@ -373,9 +525,21 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     __syncthreads();
     GEMM_STAMP(3);
 #endif
+    }
+    if (!has_next) break;
+    first_tile = false;
+    }
+#undef GEMM_PROLOGUE
+#undef GEMM_SLOT
+#undef GEMM_PIECE
+#undef FRAG_W
+#undef FRAG_A
+#undef GEMM_GLDS
+#undef GEMM_SET_TILE
+#endif
 }
 
-template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS>
+template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS, bool PIPE = false>
 static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     const int nwg = (N / BN) * ((M + BM - 1) / BM);
@@ -387,23 +551,40 @@ static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw,
     IBL_HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS>),
+        IBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS, PIPE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.fetch_or(bit, std::memory_order_release);
     }
+    int grid = nwg;
+#ifndef IBL_GEMM_PERSIST
+#define IBL_GEMM_PERSIST 1
+#endif
+    if (PIPE && IBL_GEMM_PERSIST) {          // persistent: one workgroup per CU (a multiple of 8, see GEMM_SET_TILE)
+        static std::atomic<int> n_cu{0};
+        int cus = n_cu.load(std::memory_order_relaxed);
+        if (cus == 0) {
+            IBL_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            cus = cus >= 8 ? cus / 8 * 8 : 8;
+            n_cu.store(cus, std::memory_order_relaxed);
+        }
+        if (grid > cus * OCC) grid = cus * OCC;
+    }
     void* tok;
     ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);
-    hipLaunchKernelGGL((ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS>), dim3(nwg), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS, PIPE>), dim3(grid), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
 }
 
-// Tile configurations:
-//   0  256 x 256, BK 64, 8 waves, 128 KiB LDS, 1 block / CU   (fewest operand bytes per FLOP)
+// Tile configurations (IBL_GEMM_CFG overrides the choice; the lab build -DIBL_GEMM_LAB adds the variants measured and rejected):
+//   8  256 x 256, BK 64, 8 waves, 128 KiB LDS, software-pipelined K loop, persistent grid      (default for N % 256 == 0, M >= 4096)
+//   0  256 x 256, BK 64, 8 waves, 128 KiB LDS, plain K loop, one block per tile
 //   1  128 x 128, BK 64, 4 waves,  64 KiB LDS, 2 blocks / CU  (any N % 128 == 0, small M)
 //   2  256 x 128, BK 32, 4 waves,  48 KiB LDS, 2 blocks / CU  (the epilogue of one block overlaps the K loop of the other)
 //   3  256 x 256, BK 32, 8 waves, 4 LDS stages = 128 KiB      (loads two K steps ahead, no full drain at the step boundary)
+// Measured on the four ViT-B/14 layer shapes (57 568 rows), TFLOP/s per layer, one process: 8: 783, 8 without the persistent
+// grid: 775, 0: 745, 3: 649, 2: 632, 1: 629; lab: 256 x 128 BK 32 three stages 643, 128 x 256 BK 32 639, 128 x 128 pipelined 620.
 static int gemm_cfg_override() {
     static int v = -2;
     if (v == -2) {
@@ -419,12 +600,21 @@ static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int
     if (M <= 0) return IBL_OK;
     if (N % 128 != 0 || K % GBK != 0)
         return ibl_set_error(IBL_ERR_ARG, "gemm: N (%d) must be a multiple of 128 and K (%d) of 64", N, K);
-    int cfg = (N % 256 == 0 && M >= 4096) ? 0 : 1;
+    int cfg = (N % 256 == 0 && M >= 4096) ? 8 : 1;
     const int ov = gemm_cfg_override();
-    if (ov == 1 || ov == 2 || ((ov == 0 || ov == 3) && N % 256 == 0)) cfg = ov;
+    if (ov == 1 || ov == 2 || ((ov == 0 || ov == 3 || ov == 8) && N % 256 == 0)) cfg = ov;
+#ifdef IBL_GEMM_LAB
+    if (ov == 4 || ov == 6 || ov == 7 || ov == 9 || (ov == 5 && N % 256 == 0)) cfg = ov;
+    if (cfg == 9) return launch_gemm_cfg<EPI, 4, 2, 2, 64, 2, 2, true>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 4) return launch_gemm_cfg<EPI, 8, 2, 2, 32, 2, 3>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 5) return launch_gemm_cfg<EPI, 4, 2, 4, 32, 4, 3>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 6) return launch_gemm_cfg<EPI, 4, 2, 2, 32, 2, 4>(A, lda, W, ldw, M, N, K, epi, s);
+    if (cfg == 7) return launch_gemm_cfg<EPI, 4, 2, 2, 32, 3, 3>(A, lda, W, ldw, M, N, K, epi, s);
+#endif
 #ifdef IBL_GEMM_FORCE128
     cfg = 1;
 #endif
+    if (cfg == 8) return launch_gemm_cfg<EPI, 8, 2, 4, 64, 1, 2, true>(A, lda, W, ldw, M, N, K, epi, s);
     if (cfg == 0) return launch_gemm_cfg<EPI, 8, 2, 4, 64, 1, 2>(A, lda, W, ldw, M, N, K, epi, s);
     if (cfg == 2) return launch_gemm_cfg<EPI, 8, 2, 2, 32, 2, 2>(A, lda, W, ldw, M, N, K, epi, s);
     if (cfg == 3) return launch_gemm_cfg<EPI, 8, 2, 4, 32, 1, 4>(A, lda, W, ldw, M, N, K, epi, s);

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAMPS = "--stamps" in sys.argv
 if STAMPS:                                   # `make -C instance-based-loc_amd/csrc lab` first
     sys.argv.remove("--stamps")
-    os.environ["IBLOC_LIB"] = os.path.join(ROOT, "tools", "_lab", "libibloc_lab.so")
+    os.environ.setdefault("IBLOC_LIB", os.path.join(ROOT, "tools", "_lab", "libibloc_lab.so"))
 import numpy as np
 import torch
 
