@@ -392,6 +392,17 @@ int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int
                               const ibl_instance_features* mem_features, double* T_out, double* rmse_out, double* fitness_out,
                               double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, int64_t* reuse_stats_out,
                               void* stream);
+/* ibl_register_batch_cached with an explicit RANSAC job id per job (job_ids [HOST][n_jobs]) in place of job_id_base + j: the result of
+ * a job is a function of its clouds, the seed and its id only, so a job routed to another rank (memory clouds sharded by instance
+ * range: the owner of its target instances runs it, SURVEY 8e / routing.py) returns the bits it would have returned at home.  The
+ * loop being distributed: object_memory/object_memory.py:1020-1106.  Synchronisation: as ibl_register_batch_cached. */
+int ibl_register_batch_ids(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                           int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                           int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, const uint32_t* job_ids, int n_jobs,
+                           double voxel_size, double global_dist_factor, double local_dist_factor, uint64_t seed,
+                           int64_t ransac_max_iter, int flags, const ibl_instance_features* det_features,
+                           const ibl_instance_features* mem_features, double* T_out, double* rmse_out, double* fitness_out,
+                           double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, int64_t* reuse_stats_out, void* stream);
 
 /* ---- memory build / consolidation; fp64 clouds, as the build side of the reference keeps them ---- */
 

@@ -66,6 +66,8 @@ _SIGS = {
     "ibl_register_batch_cached": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,
                                             C.c_double, C.c_uint64, C.c_uint32, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp]),
+    "ibl_register_batch_ids": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_double, C.c_double,
+                                         C.c_double, C.c_uint64, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ibl_memgrid_build": (C.c_int, [vp, vp, C.c_int64, C.c_double, C.POINTER(vp), vp]),
     "ibl_memgrid_destroy": (C.c_int, [vp]),
     "ibl_evaluate_batch": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, vp, vp]),

@@ -404,16 +404,21 @@ struct RansacState {
     long long est_k, next_i, walked, validated, last_update;
     int best_inl;
     int done;
+    unsigned job_id;          // the Philox counter word of this job: job_id_base + slot, or the caller's own id (ibl_register_batch_ids)
+    int pad_;
 };
 
 __global__ void ibl_ransac_init_kernel(RansacState* __restrict__ st, const int* __restrict__ n_corr, int J, long long max_iter,
-                                       double max_dist, int* __restrict__ active) {
+                                       double max_dist, int* __restrict__ active, unsigned job_id_base,
+                                       const unsigned* __restrict__ job_ids) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= J) return;
     RansacState s;
     for (int i = 0; i < 16; ++i) s.best_T[i] = (i % 5) == 0 ? 1.0 : 0.0;
     s.best_fit = 0; s.best_rmse = 0; s.est_k = max_iter; s.next_i = 0; s.walked = 0; s.validated = 0; s.best_inl = 0; s.last_update = -1;
     s.done = (n_corr[j] < 3 || max_dist <= 0) ? 1 : 0;
+    s.job_id = job_ids ? job_ids[j] : job_id_base + (unsigned)j;
+    s.pad_ = 0;
     st[j] = s;
     active[j] = j;           // the first rounds run every job slot (a finished job's blocks leave at once); the host compacts later
 }
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState*
     const bool job_on = !S.done;
     const float4* c = cp + 2 * (int64_t)job_off[j];
     const int nc = n_corr[j];
-    const unsigned job_id = job_id_base + (unsigned)j;
+    const unsigned job_id = S.job_id;
     __shared__ unsigned short surv[RANSAC_CHUNK];     // slot within the chunk
     __shared__ int nsurv;
     __shared__ int cnt16[4 * RANSAC_SUBS];
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(256) void ibl_ransac_transform_kernel(const RansacS
     const int j = active[lo];
     const long long i = st[j].next_i + list[e];
     double T[16];
-    ransac_hypothesis(i, job_id_base + (unsigned)j, seed_lo, seed_hi, cp + 2 * (int64_t)job_off[j], n_corr[j], max_dist, edge_sim, T);
+    ransac_hypothesis(i, st[j].job_id, seed_lo, seed_hi, cp + 2 * (int64_t)job_off[j], n_corr[j], max_dist, edge_sim, T);
     e_job[e] = j;
 #pragma unroll
     for (int t = 0; t < 12; ++t) e_T[(int64_t)e * 12 + t] = T[t];
@@ -980,6 +985,7 @@ __global__ __launch_bounds__(64) void ibl_icp_update_kernel(IcpState* __restrict
 // the fused driver
 // ------------------------------------------------------------------------------------------------
 static thread_local bool tl_force_valu = false;     // set while a call is redone after the matrix-core search overflowed its list
+static thread_local const uint32_t* tl_job_ids = nullptr;   // ibl_register_batch_ids: the caller's job ids for the duration of its call
 
 __global__ void ibl_status_clear_kernel(int* __restrict__ status, int mask) { atomicAnd(status, ~mask); }
 extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
@@ -992,6 +998,25 @@ extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const
                                      job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed, job_id_base,
                                      ransac_max_iter, flags, nullptr, nullptr, T_out, rmse_out, fitness_out, means_out, T_ransac_out,
                                      ransac_stats_out, nullptr, stream);
+}
+
+// ibl_register_batch_cached with explicit RANSAC job ids (host array, one per job): a job keeps its id -- and therefore its result, bit
+// for bit -- whichever rank and batch it is executed in (the sharded-cloud routing of routing.py).
+extern "C" int ibl_register_batch_ids(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                                      int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                                      int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, const uint32_t* job_ids, int n_jobs,
+                                      double voxel_size, double global_dist_factor, double local_dist_factor, uint64_t seed,
+                                      int64_t ransac_max_iter, int flags, const ibl_instance_features* det_features,
+                                      const ibl_instance_features* mem_features, double* T_out, double* rmse_out, double* fitness_out,
+                                      double* means_out, double* T_ransac_out, int64_t* ransac_stats_out, int64_t* reuse_stats_out, void* stream) {
+    if (!job_ids) return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_ids: null job ids");
+    tl_job_ids = job_ids;
+    const int st = ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
+                                             job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed, 0,
+                                             ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out, means_out,
+                                             T_ransac_out, ransac_stats_out, reuse_stats_out, stream);
+    tl_job_ids = nullptr;
+    return st;
 }
 
 extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
@@ -1483,7 +1508,14 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             int *active, *done_flags;
             IBL_ARENA(active, int, J + 1);
             IBL_ARENA(done_flags, int, J + 1);
-            hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist, active);
+            unsigned* d_job_ids = nullptr;
+            if (tl_job_ids) {
+                IBL_ARENA(d_job_ids, unsigned, J + 1);
+                st = ibl_stage_upload(ctx, d_job_ids, tl_job_ids, sizeof(unsigned) * (int64_t)J, s);
+                if (st) return st;
+            }
+            hipLaunchKernelGGL(ibl_ransac_init_kernel, dim3((J + 63) / 64), dim3(64), 0, s, rs, n_corr, J, (long long)ransac_max_iter, max_dist, active,
+                               job_id_base, d_job_ids);
             IBL_LAUNCH_CHECK();
             // Rounds are enqueued without asking the device anything: every per-round kernel finds the round's survivor count in
             // device memory (the last entry of the block-count scan), and the blocks of a job that has met its confidence bound

@@ -28,8 +28,8 @@ from scipy.spatial.transform import Rotation
 from . import match
 from .assign import K_HI, K_LO, assign_batch, assign_candidates
 from .parallel import ShardExchange, shard_range, sharded_candidates
-from .registration import (CloudBatch, MemGrid, RegContext, evaluate_batch, instance_features_batch, radius_outlier_batch,
-                           register_batch)
+from .registration import (CloudBatch, InstanceFeatures, MemGrid, RegContext, evaluate_batch, evaluate_points,
+                           instance_features_batch, radius_outlier_batch, register_batch)
 
 IBL_ST_GRID_OVERFLOW = 1          # ibl_reg_ctx_status bits (include/ibloc.h)
 
@@ -45,11 +45,13 @@ class MemoryShard:
     (x, y, z, intensity) and the spatial hash used by evaluate_transform.
 
     clouds=None: an embedding-only memory (BASELINE configs[3]: embed + match + assign, nothing to register against).
-    shard=(rank, world): this rank keeps the embeddings of the instances [lo, hi) = parallel.shard_range(M, rank, world) only
-    (clouds, when given, stay replicated); instance indices everywhere else remain global."""
+    shard=(rank, world): this rank keeps the embeddings of the instances [lo, hi) = parallel.shard_range(M, rank, world) only;
+    instance indices everywhere else remain global.  The clouds stay replicated unless shard_clouds=True: then this rank also keeps
+    only the clouds, cached features and evaluation grid of [lo, hi) (`clouds` / `colors` / `intensities` may be the full lists or just
+    that range), registration jobs are routed between the ranks and the evaluation is reduced over them (routing.py)."""
 
     def __init__(self, ctx: RegContext, embeddings, clouds=None, colors=None, intensities=None, eval_threshold=0.02, device="cuda",
-                 shard=None):
+                 shard=None, shard_clouds=False):
         self.ctx = ctx
         self.device = torch.device(device)
         self.M = len(embeddings)
@@ -68,6 +70,14 @@ class MemoryShard:
         self.eval_threshold = eval_threshold
         self._features = {}
         self.clouds = self.grid = None
+        self.shard_clouds = bool(shard_clouds and shard is not None and clouds is not None)
+        self.inst_sizes_all = None        # (M,) points per instance, gathered by the engine when the clouds are sharded
+        if self.shard_clouds:
+            def own_part(x):
+                return x if x is None or len(x) == self.hi - self.lo else x[self.lo:self.hi]
+            if clouds is not None and len(clouds) == self.M:
+                self.inst_sizes_all = np.array([len(c) for c in clouds], dtype=np.int64)
+            clouds, colors, intensities = own_part(clouds), own_part(colors), own_part(intensities)
         if clouds is not None:
             if intensities is None:
                 intensities = [intensity_from_colors(c) for c in colors] if colors is not None else None
@@ -123,6 +133,15 @@ class LocaliseEngine:
         # (parallel.RcclComm) when one is given; a one-rank `comm` exercises the exchange path on a single GPU
         self.exchange = ShardExchange(group, rows_cap, comm) if memory.shard is not None and (memory.shard[1] > 1 or comm is not None) else None
         self.stats = {"frames": 0, "fallback_frames": 0}        # how often the candidate search had to be redone on full rows
+        self.route = None
+        if memory.shard_clouds:                                 # collective: every rank constructs its engine
+            from .routing import Transport
+            self.route = Transport(group)
+            if memory.inst_sizes_all is None:
+                parts = self.route.all_gather_object(np.diff(memory.clouds.seg_off_host).astype(np.int64))
+                memory.inst_sizes_all = np.concatenate(parts)
+            assert len(memory.inst_sizes_all) == memory.M
+            self.route_stats = {}
 
     def close(self):
         """Releases the lane arenas (multi-GB hipMalloc each) and worker threads now instead of at garbage collection."""
@@ -273,6 +292,13 @@ class LocaliseEngine:
         runs on a second stream, driven by a worker thread, while stage B of batch k (registration) executes; results are those
         of `localise_batch`, yielded in order.  The two stages touch disjoint state: the encoder / match workspaces belong to
         stage A, the registration arena to stage B."""
+        if self.route is not None:
+            # sharded clouds: stage B has collectives of its own (routing.py); two threads issuing collectives on one group could pair
+            # them up differently on different ranks, so the batches run one after the other
+            for b in batches:
+                args = {k: b[k] for k in ("det", "q_per_frame", "crops", "det_emb", "seed", "job_id_base") if k in b}
+                yield self.localise_batch(**args, **kw)
+            return
         dev = self.memory.mem_emb.device
         side = torch.cuda.Stream(device=dev)      # equal priority: raising either stage's stream priority measured 7-8 % slower
         main = torch.cuda.current_stream(dev)
@@ -320,6 +346,53 @@ class LocaliseEngine:
                 except Exception:
                     pass
             side.synchronize()
+
+    # ---- sharded clouds: routed registration + reduced evaluation (routing.py) ------------------------------------------------
+    def _register_routed(self, ctx, clean, det_feat, mem_feat, job_src, job_tgt, job_id_base, voxel, gdf, ldf, seed, ransac_max_iter):
+        from .routing import InstanceStore, routed_register
+        mem = self.memory
+        assert det_feat is not None and mem_feat is not None, "sharded clouds need reuse_features (the cached instance features travel)"
+        arrays = {"pts": mem.clouds.pts4, "normals": mem_feat.normals, "fpfh": mem_feat.fpfh, "fpfh_split": mem_feat.fpfh_split,
+                  "fpfh_norm": mem_feat.fpfh_norm}
+        if mem_feat.grad is not None:
+            arrays["grad"] = mem_feat.grad
+        store = InstanceStore(mem.lo, mem.clouds.seg_off_host, arrays, {"bbox": mem_feat.bbox})
+
+        def compute(pool_pts, pool_off, n_home, arr, per_inst, mem_off, js, jt, ids):
+            det_pool = CloudBatch(pool_pts.contiguous(), pool_off.astype(np.int32))
+            feat = det_feat
+            if det_pool.n_seg > n_home:                      # detected segments shipped here: their features, computed where they run
+                b0 = int(pool_off[n_home])
+                extra = instance_features_batch(ctx, CloudBatch(pool_pts[b0:].contiguous(), (pool_off[n_home:] - b0).astype(np.int32)), voxel)
+                feat = InstanceFeatures(torch.cat([det_feat.normals[:clean.n], extra.normals]), torch.cat([det_feat.fpfh[:clean.n], extra.fpfh]),
+                                        torch.cat([det_feat.fpfh_split[:clean.n], extra.fpfh_split]),
+                                        torch.cat([det_feat.fpfh_norm[:clean.n], extra.fpfh_norm]), None,
+                                        np.concatenate([det_feat.bbox[:clean.n_seg], extra.bbox]), voxel, 0.0)
+            mem_pool = CloudBatch(arr["pts"].contiguous(), np.asarray(mem_off).astype(np.int32))
+            mf = InstanceFeatures(arr["normals"].contiguous(), arr["fpfh"].contiguous(), arr["fpfh_split"].contiguous(),
+                                  arr["fpfh_norm"].contiguous(), arr["grad"].contiguous() if "grad" in arr else None,
+                                  np.ascontiguousarray(per_inst["bbox"]), mem_feat.voxel_size, mem_feat.grad_radius)
+            r = register_batch(ctx, det_pool, mem_pool, js, jt, voxel, gdf, ldf, seed=seed, ransac_max_iter=ransac_max_iter,
+                               have_colors=True, center=True, det_features=feat, mem_features=mf, job_ids=ids)
+            return {k: r[k] for k in ("T", "rmse", "fitness", "means", "T_ransac", "ransac_stats")}
+
+        J = len(job_src)
+        ids = (np.uint32(job_id_base) + np.arange(J, dtype=np.uint32)).astype(np.uint32)
+        src = np.asarray(job_src, dtype=np.int64).reshape(-1, 3)
+        tgt = np.asarray(job_tgt, dtype=np.int64).reshape(-1, 3)
+        reg, _ = routed_register(self.route, mem.M, clean.pts4, clean.seg_off_host, src, tgt, ids, store, mem.inst_sizes_all, compute,
+                                 self.route_stats)
+        return reg
+
+    def _evaluate_routed(self, ctx, clean, jb, je, G, thr):
+        from .routing import routed_evaluate
+        mem = self.memory
+        thr = thr if thr is not None else mem.eval_threshold
+
+        def local(pts, b, e, T):
+            return evaluate_points(ctx, mem.grid, pts.contiguous(), b, e, T, thr)[0]
+
+        return routed_evaluate(self.route, clean.pts4, jb, je, G, local)
 
     # ---- one batch -----------------------------------------------------------------------------------------------------------
     def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
@@ -379,7 +452,7 @@ class LocaliseEngine:
                 job_frame.append(f)
                 job_src.append([int(row0[f]) + d for d, m in a] + [-1] * (3 - len(a)))
                 job_tgt.append([m for d, m in a] + [-1] * (3 - len(a)))
-        if not job_frame:
+        if not job_frame and self.route is None:        # (sharded clouds: the collectives below still need this rank)
             close_timings()
             return results
         # instance features (normals / FPFH, once per cloud instead of once per assignment): the memory's are resident (built on
@@ -389,11 +462,19 @@ class LocaliseEngine:
             det_feat = instance_features_batch(ctx, clean, fpfh_voxel_size)
             mem_feat = mem.features(fpfh_voxel_size, fpfh_local_dist_factor)
         tick("det_features")
-        reg = register_batch(ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
-                             fpfh_local_dist_factor, seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter,
-                             have_colors=True, center=True, det_features=det_feat, mem_features=mem_feat)
-        if timings is not None:
-            timings["reuse"] = reg["reuse"].tolist()
+        if self.route is not None:
+            reg = self._register_routed(ctx, clean, det_feat, mem_feat, job_src, job_tgt, job_id_base, fpfh_voxel_size,
+                                        fpfh_global_dist_factor, fpfh_local_dist_factor, seed, ransac_max_iter)
+            if not job_frame:
+                self._evaluate_routed(ctx, clean, [], [], np.zeros((0, 4, 4)), eval_threshold)
+                close_timings()
+                return results
+        else:
+            reg = register_batch(ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
+                                 fpfh_local_dist_factor, seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter,
+                                 have_colors=True, center=True, det_features=det_feat, mem_features=mem_feat)
+            if timings is not None:
+                timings["reuse"] = reg["reuse"].tolist()
         tick("register")
         # global-frame transforms (:1096-1101)
         T = reg["T"]
@@ -405,7 +486,10 @@ class LocaliseEngine:
         jb = [int(new_off_h[row0[f]]) for f in job_frame]
         je = [int(new_off_h[row0[f + 1]]) for f in job_frame]
         thr = eval_threshold if eval_threshold is not None else mem.eval_threshold
-        full_rmse, full_fit = evaluate_batch(ctx, mem.grid, clean.pts4, jb, je, G, thr)     # :1104
+        if self.route is not None:
+            full_fit, full_rmse = self._evaluate_routed(ctx, clean, jb, je, G, thr)
+        else:
+            full_rmse, full_fit = evaluate_batch(ctx, mem.grid, clean.pts4, jb, je, G, thr)     # :1104
         tick("evaluate")
         # ---- selection + pose (:1111-1131) -----------------------------------------------------------
         j = 0

@@ -184,12 +184,14 @@ REG_CENTER = 2
 
 def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_seg, job_tgt_seg, voxel_size,
                    global_dist_factor=1.5, local_dist_factor=0.4, seed=0, job_id_base=0, ransac_max_iter=4000000,
-                   have_colors=True, center=True, det_features: InstanceFeatures = None, mem_features: InstanceFeatures = None):
+                   have_colors=True, center=True, det_features: InstanceFeatures = None, mem_features: InstanceFeatures = None,
+                   job_ids=None):
     """Batched register_point_clouds (utils/fpfh_register.py:100-143).  job_*_seg: (J, <=3) int arrays of
     pool segment ids (-1 padded).  det_features / mem_features: instance features of the two pools
     (instance_features_batch); the results do not depend on them, only the work does.  Returns dict of host arrays:
     T (J,4,4), rmse, fitness, means (J,2,3), T_ransac (J,4,4), ransac_stats (J,3), reuse (points served by the instance
-    features, points recomputed, recomputed groups, job sides, distinct matching pairs, pair uses)."""
+    features, points recomputed, recomputed groups, job sides, distinct matching pairs, pair uses).
+    job_ids: (J,) explicit RANSAC ids instead of job_id_base + j (ibl_register_batch_ids: jobs routed between ranks keep theirs)."""
     def pad(a):
         a = np.asarray(a, dtype=np.int32)
         if a.ndim == 1:
@@ -211,6 +213,19 @@ def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_se
     reuse = np.zeros(6, dtype=np.int64)
     df = det_features.as_struct() if det_features is not None else None
     mf = mem_features.as_struct() if mem_features is not None else None
+    if job_ids is not None:
+        ids = np.ascontiguousarray(job_ids, dtype=np.uint32)
+        assert ids.shape == (J,)
+        st = _lib.lib.ibl_register_batch_ids(ctx.handle, det.pts4.data_ptr(), det.seg_off.data_ptr(), det.seg_off_host.ctypes.data,
+                                             det.n_seg, mem.pts4.data_ptr(), mem.seg_off.data_ptr(), mem.seg_off_host.ctypes.data,
+                                             mem.n_seg, js.ctypes.data, jt.ctypes.data, ids.ctypes.data, J, float(voxel_size),
+                                             float(global_dist_factor), float(local_dist_factor), int(seed), int(ransac_max_iter), flags,
+                                             C.byref(df) if df is not None else None, C.byref(mf) if mf is not None else None,
+                                             T.ctypes.data, rmse.ctypes.data, fit.ctypes.data, means.ctypes.data, Tr.ctypes.data,
+                                             stats.ctypes.data, reuse.ctypes.data, _stream())
+        _lib.check(st, "ibl_register_batch_ids")
+        return dict(T=T.reshape(J, 4, 4), rmse=rmse, fitness=fit, means=means, T_ransac=Tr.reshape(J, 4, 4), ransac_stats=stats,
+                    reuse=reuse)
     st = _lib.lib.ibl_register_batch_cached(ctx.handle, det.pts4.data_ptr(), det.seg_off.data_ptr(), det.seg_off_host.ctypes.data,
                                             det.n_seg, mem.pts4.data_ptr(), mem.seg_off.data_ptr(), mem.seg_off_host.ctypes.data,
                                             mem.n_seg, js.ctypes.data, jt.ctypes.data, J, float(voxel_size), float(global_dist_factor),
