@@ -499,11 +499,63 @@ __device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const Acc& ac
     }
     wave_lds_sync();
 }
+// Normals are solved in batches: a wave parks the sorted neighbour list of each query (<= NP_MAXK handles) in NormalPending and, once
+// NP_SLOTS queries are parked (or its tile is finished), every lane takes one query: covariance sums in ascending original index, then
+// the 3x3 eigen solve (~500 fp64 instructions that used to run on lane 0 alone, once per query, plus nine 64-lane fp64 reductions).
+// The sums run in the same order on every path (tile, list, query kernel), so a point's normal does not depend on which one served it.
+#define NP_SLOTS 16
+#define NP_MAXK 32
+struct NormalPending {
+    unsigned short h[NP_SLOTS][NP_MAXK];
+    int qi[NP_SLOTS];
+    int k[NP_SLOTS];
+    int n;
+};
+struct NoPending { int n; };
+
+template <class Acc, class H>
+__device__ __forceinline__ void normal_solve(const Acc& acc, const H* __restrict__ hnd, int k, int qi, float4* __restrict__ normals) {
+    double c[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) c[t] = 0.0;
+    for (int t = 0; t < k; ++t) {
+        const float4 p = acc.pt((int)hnd[t]);
+        const double x = p.x, y = p.y, z = p.z;
+        c[0] += x; c[1] += y; c[2] += z;
+        c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+    }
+    double n[3];
+    if (k >= 3) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) c[t] /= (double)k;
+        double cov[6] = {c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2],
+                         c[6] - c[1] * c[1], c[7] - c[1] * c[2], c[8] - c[2] * c[2]};
+        fast_eigen_normal_d(cov, n);
+    } else {
+        double cov[6] = {1, 0, 0, 1, 0, 1};
+        fast_eigen_normal_d(cov, n);
+    }
+    if (sqrt(dot3d(n, n)) == 0.0) { n[0] = 0; n[1] = 0; n[2] = 1; }
+    normals[qi] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.0f);
+}
+
+template <class Acc>
+__device__ __forceinline__ void normal_flush(NormalPending* P, const Acc& acc, float4* __restrict__ normals) {
+    const int lane = threadIdx.x & 63;
+    wave_lds_sync();
+    const int n = P->n;
+    if (lane < n) normal_solve(acc, P->h[lane], P->k[lane], P->qi[lane], normals);
+    wave_lds_sync();
+    if (lane == 0) P->n = 0;
+    wave_lds_sync();
+}
+
 template <class Acc>
 struct NormalConsumer {
     float4* normals;
     Acc acc;
     WaveLds* L;
+    NormalPending* P;        // null: solve at once (list / query kernels, whose handles are 32-bit)
     int qi;
     int ncount;
     __device__ void begin(int) { ncount = 0; }
@@ -516,28 +568,14 @@ struct NormalConsumer {
     __device__ void finish(int k) {
         const int lane = threadIdx.x & 63;
         sort_selected_by_index<false>(L, acc, k);
-        double c[9];
-        for (int t = 0; t < 9; ++t) c[t] = 0.0;
-        for (int t = lane; t < k; t += 64) {
-            const float4 p = acc.pt(L->b_j[t]);
-            const double x = p.x, y = p.y, z = p.z;
-            c[0] += x; c[1] += y; c[2] += z;
-            c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
-        }
-        for (int t = 0; t < 9; ++t) c[t] = wave_sum_d(c[t]);
-        if (lane == 0) {
-            double n[3];
-            if (k >= 3) {
-                for (int t = 0; t < 9; ++t) c[t] /= (double)k;
-                double cov[6] = {c[3] - c[0] * c[0], c[4] - c[0] * c[1], c[5] - c[0] * c[2],
-                                 c[6] - c[1] * c[1], c[7] - c[1] * c[2], c[8] - c[2] * c[2]};
-                fast_eigen_normal_d(cov, n);
-            } else {
-                double cov[6] = {1, 0, 0, 1, 0, 1};
-                fast_eigen_normal_d(cov, n);
-            }
-            if (sqrt(dot3d(n, n)) == 0.0) { n[0] = 0; n[1] = 0; n[2] = 1; }
-            normals[qi] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.0f);
+        if (P != nullptr && k <= NP_MAXK) {
+            const int slot = P->n;
+            if (lane < k) P->h[slot][lane] = (unsigned short)L->b_j[lane];
+            if (lane == 0) { P->qi[slot] = qi; P->k[slot] = k; P->n = slot + 1; }
+            if (slot + 1 == NP_SLOTS) normal_flush(P, acc, normals);
+            else wave_lds_sync();
+        } else if (lane == 0) {
+            normal_solve(acc, L->b_j, k, qi, normals);
         }
     }
 };
@@ -801,7 +839,8 @@ struct NeedPop { float v[8]; int rho_start; };
 
 template <int TS, class TL, class Factory>
 __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int max_nn, const NeedPop& need_pop, int* __restrict__ fb_list,
-                               int* __restrict__ fb_count, const Factory& fac, int q_lo, int q_hi, TL& T, WaveLds* wl) {
+                               int* __restrict__ fb_count, const Factory& fac, int q_lo, int q_hi, TL& T, WaveLds* wl,
+                               typename Factory::Pending* pend) {
     constexpr int KT_CAP = TL::CAP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
@@ -902,6 +941,10 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     const float fy0 = y0 > 0 ? sg.miny + (float)y0 * cellw + mgn : -INFINITY, fy1 = y1 < sg.ny - 1 ? sg.miny + (float)(y1 + 1) * cellw - mgn : INFINITY;
     const float fz0 = z0 > 0 ? sg.minz + (float)z0 * cellw + mgn : -INFINITY, fz1 = z1 < sg.nz - 1 ? sg.minz + (float)(z1 + 1) * cellw - mgn : INFINITY;
     WaveLds* L = &wl[wave];
+    typename Factory::Pending* P = &pend[wave];
+    if (lane == 0) P->n = 0;
+    wave_lds_sync();
+    const TileAcc tacc{T.pts, T.ord};
     int run_r = 0;
     for (int qk = wave; qk < nq; qk += 4) {
         while (qk >= T.q_off[run_r + 1]) ++run_r;
@@ -914,26 +957,31 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
             float cover = fminf(fminf(q.x - fx0, fx1 - q.x), fminf(fminf(q.y - fy0, fy1 - q.y), fminf(q.z - fz0, fz1 - q.z)));
             if (cover < 0.f) cover = 0.f;
             const float cover2 = cover >= radius ? INFINITY : cover * cover;
-            auto cons = fac.template make<TileAcc>(qi, q, L, TileAcc{T.pts, T.ord});
+            auto cons = fac.template make<TileAcc>(qi, q, L, tacc, P);
             done = tile_select(T, total, q, cover2, r2, max_nn, L, cons);
         }
         // not provable from the staged cube (sparse spot, LDS budget, boundary-bin overflow): the query joins the list of the
         // per-query grid walk that runs after this kernel (ibl_knn_list_kernel)
         if (!done && lane == 0) fb_list[atomicAdd(fb_count, 1)] = jq;
     }
+    fac.flush(P, tacc);                     // the queries still parked (NormalFactory)
 }
 
 struct NormalFactory {
+    typedef NormalPending Pending;
     float4* normals;
-    template <class Acc> __device__ NormalConsumer<Acc> make(int qi, const float4&, WaveLds* L, const Acc& acc) const {
+    template <class Acc> __device__ NormalConsumer<Acc> make(int qi, const float4&, WaveLds* L, const Acc& acc, Pending* P = nullptr) const {
         NormalConsumer<Acc> c;
-        c.normals = normals; c.acc = acc; c.L = L; c.qi = qi; c.ncount = 0;
+        c.normals = normals; c.acc = acc; c.L = L; c.P = P; c.qi = qi; c.ncount = 0;
         return c;
     }
+    template <class Acc> __device__ void flush(Pending* P, const Acc& acc) const { normal_flush(P, acc, normals); }
 };
 struct SpfhFactory {
+    typedef NoPending Pending;
     const float4* normals; unsigned char* spfh_cnt; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K;
-    template <class Acc> __device__ SpfhConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc) const {
+    template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
+    template <class Acc> __device__ SpfhConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc, Pending* = nullptr) const {
         SpfhConsumer<Acc> c;
         c.normals = normals; c.acc = acc; c.spfh_cnt = spfh_cnt; c.nbr_idx = nbr_idx; c.nbr_d2 = nbr_d2; c.nbr_cnt = nbr_cnt; c.K = K;
         c.qi = qi; c.q = q; c.qn = normals[qi]; c.L = L; c.ncount = 0;
@@ -941,8 +989,10 @@ struct SpfhFactory {
     }
 };
 struct GradFactory {
+    typedef NoPending Pending;
     const float4* normals; float4* grad;
-    template <class Acc> __device__ GradConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc) const {
+    template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
+    template <class Acc> __device__ GradConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc, Pending* = nullptr) const {
         GradConsumer<Acc> c;
         c.normals = normals; c.acc = acc; c.grad = grad; c.qi = qi; c.q = q; c.qn = normals[qi]; c.L = L; c.ncount = 0;
         return c;
@@ -955,7 +1005,8 @@ __global__ __launch_bounds__(256) void ibl_knn_tile_kernel(BatchGrid g, float ra
                                                            int q_lo, int q_hi, int* __restrict__ fb_list, int* __restrict__ fb_count) {
     __shared__ TileLds<CAP> T;
     __shared__ WaveLds wl[4];
-    tile_knn_block<TS>(g, radius, r2, max_nn, need_pop, fb_list, fb_count, fac, q_lo, q_hi, T, wl);
+    __shared__ typename Factory::Pending pend[4];
+    tile_knn_block<TS>(g, radius, r2, max_nn, need_pop, fb_list, fb_count, fac, q_lo, q_hi, T, wl, pend);
 }
 
 // the queries the tile kernel could not answer from its staged cubes: one wavefront each, walking the grid (sorted positions in list)
