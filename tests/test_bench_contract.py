@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01/bench_default.json, produced by `python bench.py` on an MI355X) keeps the driver's contract."""
+"""The committed bench line (profiles/r02/bench_default.json, produced by `python bench.py` on an MI355X) keeps the driver's contract."""
 import json
 import os
 
@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r01", "bench_default.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r02", "bench_default.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
@@ -22,3 +22,6 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - d["config"]["frames_per_step_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # round 2: the default workload is BASELINE's metric row (M = 10 000) and says how honest the synthetic detections are
+    assert d["config"]["memory_instances"] == 10000 and d["config"]["workload"].startswith("T:")
+    assert d["det_points_after_outlier_mean"] >= 4000 and d["assignment_correct_rate"] >= 0.95 and d["registered_given_correct_assignment"] >= 0.95
