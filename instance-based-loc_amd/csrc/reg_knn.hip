@@ -1069,34 +1069,49 @@ __device__ __forceinline__ double div_by_rcp(double x, double d, double y) {
     return fma(fma(-q1, d, x), y, q1);
 }
 
+// A workgroup serves FPFH_Q = 7 points: thread p < 231 owns (point p / 33, bin p % 33), so 231 of its 256 lanes work (one wave per
+// point left 31 of 64 idle in the loop below, which is the whole kernel).  Neighbour rows are staged 64 per point at a time; each
+// (point, bin) sum runs over the neighbour list in its stored order, exactly as before.
+#define FPFH_Q 7
 __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __restrict__ spfh_cnt, const int* __restrict__ nbr_idx,
                                                        const float* __restrict__ nbr_d2, const int* __restrict__ nbr_cnt, int K, int n,
                                                        int matching_order, float* __restrict__ fpfh) {
-    __shared__ FpfhTile tiles[4];
-    FpfhTile& T = tiles[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= n) return;
-    const int k = nbr_cnt[qi];
+    __shared__ FpfhTile tiles[FPFH_Q];
+    __shared__ double accs[FPFH_Q][33];
+    __shared__ int kq[FPFH_Q];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * FPFH_Q;
+    if (tid < FPFH_Q) kq[tid] = q0 + tid < n ? nbr_cnt[q0 + tid] : 0;
+    __syncthreads();
+    int kmax = 0;
+#pragma unroll
+    for (int u = 0; u < FPFH_Q; ++u) kmax = max(kmax, kq[u]);
+    const int qq = tid / 33, b = tid - qq * 33;            // tid >= 231: no work (qq == 7)
+    const bool mine = qq < FPFH_Q && q0 + qq < n;
+    const int qi = q0 + qq;
+    const int k = mine ? kq[qq] : 0;
     double acc = 0.0;
-    const int b = lane < 33 ? lane : 32;
-    if (k > 1) {
-        for (int t0 = 0; t0 < k; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < k) {
-                const int j = nbr_idx[(int64_t)qi * K + t];
-                const double dist = (double)nbr_d2[(int64_t)qi * K + t];
+    for (int t0 = 0; t0 < kmax; t0 += 64) {
+        for (int e = tid; e < FPFH_Q * 64; e += 256) {     // stage row t0 + r of point sq
+            const int sq = e >> 6, r = e & 63, t = t0 + r, si = q0 + sq;
+            if (si < n && t < kq[sq]) {
+                FpfhTile& S = tiles[sq];
+                const int j = nbr_idx[(int64_t)si * K + t];
+                const double dist = (double)nbr_d2[(int64_t)si * K + t];
                 const int kj = nbr_cnt[j];
                 const unsigned int* src = reinterpret_cast<const unsigned int*>(spfh_cnt + (int64_t)j * 36);
-                unsigned int* dst = reinterpret_cast<unsigned int*>(T.cnt[lane]);
+                unsigned int* dst = reinterpret_cast<unsigned int*>(S.cnt[r]);
 #pragma unroll
                 for (int w = 0; w < 9; ++w) dst[w] = src[w];
-                T.inc[lane] = kj > 1 ? 100.0 / (double)(kj - 1) : 0.0;
-                const bool skip = j == qi || dist == 0.0;
-                T.dist[lane] = skip ? -1.0 : dist;
-                T.rcp[lane] = skip ? 0.0 : 1.0 / dist;
+                S.inc[r] = kj > 1 ? 100.0 / (double)(kj - 1) : 0.0;
+                const bool skip = j == si || dist == 0.0;
+                S.dist[r] = skip ? -1.0 : dist;
+                S.rcp[r] = skip ? 0.0 : 1.0 / dist;
             }
-            wave_lds_sync();
+        }
+        __syncthreads();
+        if (mine && k > 1) {
+            const FpfhTile& T = tiles[qq];
             const int m = min(64, k - t0);
             for (int r = 0; r < m; ++r) {
                 const double dist = T.dist[r];
@@ -1106,20 +1121,22 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
                 const float sp = (float)((double)cb * T.inc[r]);
                 acc += div_by_rcp((double)sp, dist, T.rcp[r]);
             }
-            wave_lds_sync();
         }
+        __syncthreads();
     }
-    // block sums over bins 0-10, 11-21, 22-32
-    double sum = 0.0;
-    const int blk = b / 11;
-    for (int t = 0; t < 11; ++t) sum += __shfl(acc, blk * 11 + t, 64);
-    if (lane < 33) {
+    if (mine) accs[qq][b] = acc;
+    __syncthreads();
+    if (mine) {
+        // block sums over bins 0-10, 11-21, 22-32
+        double sum = 0.0;
+        const int blk = b / 11;
+        for (int t = 0; t < 11; ++t) sum += accs[qq][blk * 11 + t];
         float out = 0.0f;
         if (k > 1) {
             const double sc = sum != 0.0 ? 100.0 / sum : 0.0;
-            out = (float)(acc * sc + (double)spfh_value(spfh_cnt, nbr_cnt, qi, lane));
+            out = (float)(acc * sc + (double)spfh_value(spfh_cnt, nbr_cnt, qi, b));
         }
-        fpfh[(int64_t)qi * 33 + (matching_order ? FEAT_POS[lane] : lane)] = out;
+        fpfh[(int64_t)qi * 33 + (matching_order ? FEAT_POS[b] : b)] = out;
     }
 }
 
@@ -1214,7 +1231,7 @@ int ibl_launch_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, con
     const int st = launch_knn(ctx, g, pts, seg_off, n, 0, n, radius, max_nn, SpfhFactory{normals, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn}, status, s);
     ibl_prof_end(tok, s);
     if (st) return st;
-    hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, matching_order, fpfh);
+    hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + FPFH_Q - 1) / FPFH_Q), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, matching_order, fpfh);
     IBL_LAUNCH_CHECK();
     return IBL_OK;
 }
