@@ -36,7 +36,10 @@
 typedef __attribute__((ext_vector_type(8))) _Float16 fm_h16x8;
 typedef __attribute__((ext_vector_type(16))) float fm_f32x16;
 
-#define FM_DT 32                 // database rows per chunk (one 32 x 32 MFMA tile per wave)
+#ifndef FM_SUB
+#define FM_SUB 1                 // 32-row MFMA tiles per chunk (one workgroup barrier per chunk); 2 / 4 measured 4 % / 14 % slower per registration call
+#endif
+#define FM_DT (32 * FM_SUB)      // database rows per chunk
 #define FM_ROWB 112              // LDS bytes per row: 48 fp16 + 16 pad (2-way instead of 4-way bank conflicts on ds_read_b128)
 #define FM_C 1.0e-3f             // E = FM_C (|q|^2 + |t|^2)
 #define FM_NS 8.0f               // norms are stored divided by 8 (|x|^2 reaches 1.2e5, fp16 ends at 65 504) against a constant 8
@@ -109,16 +112,23 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
     // end of the database get a squared norm beyond any real bound instead (terms 35 / 36; d2 <= 2 N <= 4.8e5 for FPFH rows, whose
     // histograms sum to 200), so that they are never the minimum of pass 1; pass 2 checks the row index
     const int n_chunks = (P.dcnt + FM_DT - 1) / FM_DT;
-    uint4 pre0 = make_uint4(0, 0, 0, 0);
-    const int r0 = tid / 6, p0 = tid - r0 * 6;
+    constexpr int NPIECE = FM_DT * 6, PPT = (NPIECE + 255) / 256;          // 16-byte pieces of a chunk, per thread
+    uint4 pre[PPT];
+    int pr[PPT], pp[PPT];
+#pragma unroll
+    for (int v = 0; v < PPT; ++v) { pre[v] = make_uint4(0, 0, 0, 0); pr[v] = (tid + 256 * v) / 6; pp[v] = (tid + 256 * v) - pr[v] * 6; }
     auto fetch = [&](int t0) {
-        if (tid < 192) {
-            if (t0 + r0 < P.dcnt) pre0 = ds[(int64_t)(t0 + r0) * 6 + p0];
-            else pre0 = p0 == 4 ? make_uint4(0, 0x7BFFu << 16, 0x7BFFu, 0) : make_uint4(0, 0, 0, 0);      // terms 35, 36 = 65 504: a bound of 1.05e6 > 2 N
-        }
+#pragma unroll
+        for (int v = 0; v < PPT; ++v)
+            if (tid + 256 * v < NPIECE) {
+                if (t0 + pr[v] < P.dcnt) pre[v] = ds[(int64_t)(t0 + pr[v]) * 6 + pp[v]];
+                else pre[v] = pp[v] == 4 ? make_uint4(0, 0x7BFFu << 16, 0x7BFFu, 0) : make_uint4(0, 0, 0, 0);      // terms 35, 36 = 65 504: a bound of 1.05e6 > 2 N
+            }
     };
     auto stash = [&](FmTile& T) {
-        if (tid < 192) *reinterpret_cast<uint4*>(T.rows + r0 * FM_ROWB + 16 * p0) = pre0;
+#pragma unroll
+        for (int v = 0; v < PPT; ++v)
+            if (tid + 256 * v < NPIECE) *reinterpret_cast<uint4*>(T.rows + pr[v] * FM_ROWB + 16 * pp[v]) = pre[v];
     };
     __shared__ int2 queue[PASS == 2 ? 4 : 1][PASS == 2 ? FM_QUEUE : 1];
     int qcount = 0;                                  // wave-uniform
@@ -143,6 +153,15 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
         FmTile& T = tiles[c & 1];
         const bool more = c + 1 < n_chunks;
         if (more) fetch((c + 1) * FM_DT);
+        // all fragment reads of the chunk first: the MFMAs of its first 32 rows run while the later reads return
+        fm_h16x8 ah[FM_SUB][3];
+#pragma unroll
+        for (int h = 0; h < FM_SUB; ++h)
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+                ah[h][s3] = *reinterpret_cast<const fm_h16x8*>(T.rows + (32 * h + n) * FM_ROWB + 32 * s3 + 16 * kg);
+#pragma unroll
+        for (int h = 0; h < FM_SUB; ++h) {
         fm_f32x16 acc[FM_NQ];
 #pragma unroll
         for (int u = 0; u < FM_NQ; ++u)
@@ -150,10 +169,9 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
             for (int i = 0; i < 16; ++i) acc[u][i] = 0.0f;
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
-            // A operand: lane (m = n, kg) holds terms 16 s + 8 kg + 0..7 of database row m
-            const fm_h16x8 ah = *reinterpret_cast<const fm_h16x8*>(T.rows + n * FM_ROWB + 32 * s3 + 16 * kg);
+            // A operand: lane (m = n, kg) holds terms 16 s + 8 kg + 0..7 of database row 32 h + m of the chunk
 #pragma unroll
-            for (int u = 0; u < FM_NQ; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[u][s3], acc[u], 0, 0, 0);
+            for (int u = 0; u < FM_NQ; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[h][s3], qh[u][s3], acc[u], 0, 0, 0);
         }
         // acc[u][i] = the bound (d2_approx + E in pass 1, - E in pass 2) of database row m = 8 (i / 4) + 4 kg + (i % 4) of the chunk
         // and query n of tile u
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
                 // (two million same-address atomics per step took longer than the whole search)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int row = c * FM_DT + 8 * (i >> 2) + 4 * kg + (i & 3);
+                    const int row = c * FM_DT + 32 * h + 8 * (i >> 2) + 4 * kg + (i & 3);
                     const bool hit = valid[u] && acc[u][i] <= mup[u] && row < P.dcnt;
                     const unsigned long long m = __ballot(hit);
                     if (m) {
@@ -180,6 +198,7 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
                     }
                 }
             }
+        }
         }
         if (more) stash(tiles[(c + 1) & 1]);        // the other buffer: its readers passed the barrier that ended chunk c - 1
         __syncthreads();
