@@ -282,10 +282,15 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank flow on a one-GPU box (not a measurement): IBL_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # uses gloo for the barrier / max-over-ranks (RCCL refuses two ranks on one device)
+    share_gpu = os.environ.get("IBL_BENCH_SHARE_GPU", "") == "1"
+    if share_gpu:
+        local_rank = 0
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if share_gpu else "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     device = f"cuda:{local_rank}"
@@ -328,7 +333,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world_size > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_frames = args.frames * args.steps * world_size
