@@ -62,3 +62,66 @@ def test_oracle_registers_a_real_view_against_the_saved_objects(view, objs_seen)
     rerr = np.arccos(np.clip((np.trace(R.T @ T[:3, :3]) - 1) / 2, -1, 1))
     assert terr < 0.6 and rerr < 0.3, (terr, rerr)
     assert recs[best]["fitness"] > 0.5 and recs[best]["full_fitness"] > 0.5
+
+
+def _fpfh_independent(P, N, radius, max_nn):
+    """Open3D's FPFH formulas (Feature.cpp ComputeFPFHFeature) restated with array arithmetic in float64 on
+    scipy's kd-tree neighbourhoods -- shares no code, summation order or search structure with oracle/oracle_reg.c."""
+    n = len(P)
+    d, idx = cKDTree(P).query(P, k=max_nn)
+    ok = d < radius                                                   # hybrid search: at most max_nn neighbours, strictly inside the radius
+    cnt = ok.sum(1)
+    d2 = d * d
+    p1, n1 = P[:, None, :], N[:, None, :]
+    p2, n2 = P[idx], N[idx]
+    dv = p2 - p1
+    r = np.linalg.norm(dv, axis=2)
+    rs_ = np.where(r > 0, r, 1.0)
+    a1 = (n1 * dv).sum(2) / rs_
+    a2 = (n2 * dv).sum(2) / rs_
+    swap = np.arccos(np.clip(np.abs(a1), 0, 1)) > np.arccos(np.clip(np.abs(a2), 0, 1))
+    na = np.where(swap[..., None], n2, n1)
+    nb = np.where(swap[..., None], n1, n2)
+    dd = np.where(swap[..., None], -dv, dv)
+    f3 = np.where(swap, -a2, a1)
+    v = np.cross(dd, na)
+    vn = np.linalg.norm(v, axis=2)
+    good = (r > 0) & (vn > 0)
+    v = v / np.where(vn > 0, vn, 1.0)[..., None]
+    w = np.cross(na, v)
+    f1 = np.arctan2((w * nb).sum(2), (na * nb).sum(2))
+    f2 = (v * nb).sum(2)
+    f1, f2, f3 = (np.where(good, f, 0.0) for f in (f1, f2, f3))
+    h = np.stack([np.floor(11 * (f1 + np.pi) / (2 * np.pi)), np.floor(11 * (f2 + 1) * 0.5), np.floor(11 * (f3 + 1) * 0.5)], axis=2)
+    h = np.clip(h, 0, 10).astype(np.int64) + np.array([0, 11, 22])
+    use = ok & (idx != np.arange(n)[:, None]) & (cnt > 1)[:, None]
+    inc = np.where(cnt > 1, 100.0 / np.maximum(cnt - 1, 1), 0.0)
+    spfh = np.zeros((n, 33))
+    rows = np.repeat(np.arange(n), max_nn * 3).reshape(n, max_nn, 3)
+    np.add.at(spfh, (rows[use], h[use]), np.repeat(inc, max_nn * 3).reshape(n, max_nn, 3)[use])
+    wgt = np.where(use & (d2 > 0), 1.0 / np.where(d2 > 0, d2, 1.0), 0.0)
+    acc = (spfh[idx] * wgt[..., None]).sum(1)
+    s = acc.reshape(n, 3, 11).sum(2)
+    sc = np.where(s != 0, 100.0 / np.where(s != 0, s, 1.0), 0.0)
+    out = acc * np.repeat(sc, 11, axis=1) + spfh
+    out[cnt <= 1] = 0.0
+    return out, cnt
+
+
+def test_oracle_fpfh_on_a_real_object_matches_an_independent_restatement():
+    """the independent checks of the registration oracle ran on 400-point synthetic clouds only.  Here: the
+    reference's own 11 209-point object (5 mm surface sampling: every 0.25 m neighbourhood saturates the 100-neighbour cap, the
+    regime the hot path lives in), normals from the oracle, FPFH from an array restatement that shares nothing with it."""
+    P32 = rs.memory_objects()[0][0].astype(np.float32)
+    nrm = ro.normals(P32, 0.1, 30)
+    got = ro.fpfh(P32, nrm, 0.25, 100)
+    exp, cnt = _fpfh_independent(P32.astype(np.float64), nrm.astype(np.float64), 0.25, 100)
+    assert np.mean(cnt == 100) > 0.99                                  # saturated neighbourhoods
+    row_err = np.abs(got - exp).max(1)
+    # equidistant neighbours at the 100th place (a 5 mm lattice has many) may be chosen differently, and a pair feature within an
+    # ulp of a bin edge may fall on either side: a few rows move by one histogram count (100 / 99 per count, before weighting)
+    # measured: median 3.7e-6, 99.78 % of the rows within 1e-2, 99.99 % within 0.5
+    assert np.median(row_err) < 1e-5 and np.mean(row_err < 1e-2) > 0.995 and np.mean(row_err < 0.5) > 0.9995, (
+        float(np.median(row_err)), float(np.mean(row_err < 1e-2)), float(np.mean(row_err < 0.5)))
+    sums = got.reshape(len(got), 3, 11).sum(-1)
+    assert np.all(np.abs(sums - 200) < 0.05)
