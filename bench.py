@@ -157,9 +157,11 @@ def build_workload(args, rank, world_size, device):
     if args.shard_memory and args.comm == "rccl":            # the library's own RCCL communicator instead of torch.distributed's group
         from ibloc_amd.parallel import RcclComm
         comm = RcclComm() if world_size > 1 else RcclComm.single()
-    shard = (rank, world_size) if args.shard_memory and (world_size > 1 or comm is not None) else None
+    shard = (rank, world_size) if (args.shard_memory and (world_size > 1 or comm is not None)) or args.shard_clouds else None
+    # --shard-clouds: this rank keeps the clouds / cached features / evaluation grid of its instance range only; registration jobs are
+    # routed between the ranks (ibloc_amd/routing.py).  At one rank it runs the routed path with every instance local.
     mem = MemoryShard(ctx, list(mem_emb), world.points if args.register else None, colors=world.colors if args.register else None,
-                      device=device, shard=shard)
+                      device=device, shard=shard, shard_clouds=args.shard_clouds)
     # host cores are shared by the ranks of the node: the assignment search takes its share, at most 16 threads
     cores = host_cores()
     eng = LocaliseEngine(mem, enc, assign_threads=max(1, min(16, cores // max(1, world_size))), rows_cap=args.frames * 7, comm=comm)
@@ -266,6 +268,8 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="run the steps back to back instead of pipelined")
     ap.add_argument("--shard-memory", action="store_true", help="shard the embedding memory by instance range over the ranks "
                     "(per-shard candidate top-k + RCCL all-gather) instead of replicating it")
+    ap.add_argument("--shard-clouds", action="store_true", help="also shard the memory clouds by instance range: registration jobs run at "
+                    "the owner of their targets or fetch the instances they miss, whole-memory evaluation is reduced over the ranks")
     ap.add_argument("--comm", default="torch", choices=["torch", "rccl"], help="transport of the --shard-memory collectives: "
                     "torch.distributed's nccl (= RCCL) group, or the library's own RCCL communicator (ibl_comm_*)")
     args = ap.parse_args()
@@ -403,7 +407,8 @@ def main():
             "config": {"workload": f"{args.config}: {args.model} {crop_desc} (Q={args.q}), {args.memory}-instance memory (E={args.views}), {stages}",
                        "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
                        "points_per_object": args.points,
-                       "parallelism": f"frames-dp{world_size}" + ("+memory-shard%d(%s)" % (world_size, args.comm) if args.shard_memory else "")},
+                       "parallelism": f"frames-dp{world_size}" + ("+memory-shard%d(%s)" % (world_size, args.comm) if args.shard_memory else "")
+                       + ("+cloud-shard%d" % world_size if args.shard_clouds else "")},
             # `roofline`: HIP events around every GEMM launch of the timed region.  With pipelined steps the embed stream shares the
             # device with the registration kernels of the previous step, so a launch's duration there is not the kernel's own
             # speed; `roofline_isolated` is the same measurement over the launches of one extra step run alone afterwards.

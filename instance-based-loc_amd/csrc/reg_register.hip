@@ -1104,30 +1104,46 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     {
         // With the instance boxes on the host (instance features carry them) the table is sized from an upper bound of every job
         // side's extent -- centring moves a side, it does not stretch it beyond rounding -- and the build needs no read-back.
-        int64_t bound = 0;
-        bool have = det_features && mem_features && det_features->bbox && mem_features->bbox;
-        for (int sgi = 0; sgi < 2 * J && have; ++sgi) {
-            const int pl = sgi >= J ? 1 : 0, j = pl ? sgi - J : sgi;
-            const int* segs = pl ? jobs[j].tgt_seg : jobs[j].src_seg;
-            const int* off = pl ? mem_off_host : det_off_host;
-            const float* boxes = pl ? mem_features->bbox : det_features->bbox;
-            float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-            bool any = false;
-            for (int t = 0; t < 3; ++t) {
-                if (segs[t] < 0 || off[segs[t] + 1] == off[segs[t]]) continue;
-                const float* b = boxes + 6 * (size_t)segs[t];
-                for (int c = 0; c < 3; ++c) { lo[c] = any ? std::min(lo[c], b[c]) : b[c]; hi[c] = any ? std::max(hi[c], b[3 + c]) : b[3 + c]; }
-                any = true;
+        // A batch with many spread-out job sides (assignments to instances far apart) would not fit the cell budget at the nominal cell
+        // size: the cell grows until it does.  The neighbour walk derives its reach from the cell size, so only the work changes.
+        const bool have = det_features && mem_features && det_features->bbox && mem_features->bbox;
+        const int64_t budget = (int64_t)128 << 20;
+        float cellC = (float)(max_dist_icp / ICP_CELL_DIV);
+        auto bound_for = [&](float cell0) -> int64_t {
+            int64_t bound = 0;
+            for (int sgi = 0; sgi < 2 * J; ++sgi) {
+                const int pl = sgi >= J ? 1 : 0, j = pl ? sgi - J : sgi;
+                const int* segs = pl ? jobs[j].tgt_seg : jobs[j].src_seg;
+                const int* off = pl ? mem_off_host : det_off_host;
+                const float* boxes = pl ? mem_features->bbox : det_features->bbox;
+                float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                bool any = false;
+                for (int t = 0; t < 3; ++t) {
+                    if (segs[t] < 0 || off[segs[t] + 1] == off[segs[t]]) continue;
+                    const float* b = boxes + 6 * (size_t)segs[t];
+                    for (int c = 0; c < 3; ++c) { lo[c] = any ? std::min(lo[c], b[c]) : b[c]; hi[c] = any ? std::max(hi[c], b[3 + c]) : b[3 + c]; }
+                    any = true;
+                }
+                double cells = 1;
+                float cell = cell0;
+                const float emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+                if (emax * 1.0001f / 128.0f > cell) cell = emax / 128.0f;
+                for (int c = 0; c < 3; ++c) cells *= std::floor((double)(hi[c] - lo[c]) * 1.0001 / cell) + 2.0;
+                bound += (int64_t)cells;
             }
-            double cells = 1;
-            float cell = (float)(max_dist_icp / ICP_CELL_DIV);
-            const float emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-            if (emax * 1.0001f / 128.0f > cell) cell = emax / 128.0f;
-            for (int c = 0; c < 3; ++c) cells *= std::floor((double)(hi[c] - lo[c]) * 1.0001 / cell) + 2.0;
-            bound += (int64_t)cells;
+            return bound;
+        };
+        int64_t bound = have ? bound_for(cellC) : 0;
+        for (int tries = 0; have && bound >= budget && tries < 12; ++tries) { cellC *= 1.5f; bound = bound_for(cellC); }
+        if (have && bound < budget) {
+            st = ibl_build_batch_grid_bounded(ctx, P, d_job_off, job_off.data(), 2 * J, cellC, bound, &gC, s);
+        } else {
+            for (int tries = 0; tries < 8; ++tries) {
+                st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, cellC, budget, &gC, s);
+                if (st != IBL_ERR_OVERFLOW) break;
+                cellC *= 2.0f;
+            }
         }
-        if (have && bound < ((int64_t)128 << 20)) st = ibl_build_batch_grid_bounded(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(max_dist_icp / ICP_CELL_DIV), bound, &gC, s);
-        else st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, (float)(max_dist_icp / ICP_CELL_DIV), (int64_t)128 << 20, &gC, s);
     }
     if (st) return st;
     phase("grid C");

@@ -91,3 +91,30 @@ def test_evaluate_zero_length_range_and_far_transform(ctx):
     rmse, fit = evaluate_batch(ctx, grid, det.pts4, [0, 0, 5], [300, 300, 5], np.stack([np.eye(4), far, np.eye(4)]), 0.02)
     assert fit[0] == 1.0 and rmse[0] == 0.0 and fit[1] == 0.0 and fit[2] == 0.0
     grid.close()
+
+
+def test_many_spread_out_jobs_fit_the_icp_grid_budget(ctx):
+    """Jobs whose target instances are far apart (a wrong assignment on real data) span tens of metres; a batch of them used to exceed the
+    128 M-cell budget of the ICP grid at the nominal 3.75 cm cell and fail the whole call.  The cell now grows until the batch fits; the
+    neighbour search is exact at any cell size, so every job still returns what it returns in a batch of its own."""
+    from ibloc_amd.registration import CloudBatch, instance_features_batch, register_batch
+    w = SynthWorld(4, pts_per_object=1500, E=1, D=8, seed=91)
+    rng = np.random.default_rng(92)
+    far = [np.float32([0, 0, 0]), np.float32([60, 0, 0]), np.float32([0, 70, 0]), np.float32([55, 65, 20])]
+    mem_clouds = [w.points[i].astype(np.float32) + far[i] for i in range(4)]
+    ints = [rng.uniform(0.1, 0.9, size=len(c)).astype(np.float32) for c in mem_clouds]
+    mem = CloudBatch.from_numpy(mem_clouds, ints)
+    det = CloudBatch.from_numpy([c + np.float32([0.02, -0.01, 0.03]) for c in mem_clouds], ints)
+    mf = instance_features_batch(ctx, mem, 0.05, 2 * 0.05 * 1.5)
+    df = instance_features_batch(ctx, det, 0.05)
+    J = 72                                                         # 72 sides of ~129^3 cells each: 150 M cells at the nominal cell
+    src = [[j % 4, (j + 1) % 4, -1] for j in range(J)]
+    tgt = [[j % 4, (j + 1) % 4, -1] for j in range(J)]
+    ids = np.arange(500, 500 + J, dtype=np.uint32)
+    kw = dict(voxel_size=0.05, global_dist_factor=1.5, local_dist_factor=1.5, seed=9, det_features=df, mem_features=mf)
+    big = register_batch(ctx, det, mem, src, tgt, job_ids=ids, **kw)
+    assert ctx.status() & 1 == 0                                   # no grid overflow flag
+    for j in (0, 1, 37, 71):
+        one = register_batch(ctx, det, mem, [src[j]], [tgt[j]], job_ids=ids[j:j + 1], **kw)
+        assert np.array_equal(one["T"][0], big["T"][j]) and one["fitness"][0] == big["fitness"][j]
+        assert big["fitness"][j] > 0.5
