@@ -444,11 +444,6 @@ __device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const Acc& ac
     const int lane = threadIdx.x & 63;
     if (lane == 0) { L->scratch[62] = 0x7FFFFFFF; L->scratch[63] = -1; }
     wave_lds_sync();
-#ifdef KNN_LAB_NO_SORT
-    for (int t = lane; t < k; t += 64) { L->b_j[t] = L->sel_j[t]; if (WITH_D2) L->b_bits[t] = __float_as_uint(L->sel_d2[t]); }
-    wave_lds_sync();
-    return;
-#endif
     for (int t = lane; t < k; t += 64) {
         const int key = acc.ord(L->sel_j[t]);
         L->b_idx[t] = key;
@@ -650,11 +645,7 @@ struct SpfhConsumer {
             nbr_d2[(int64_t)qi * K + t] = __uint_as_float(L->b_bits[t]);
             if (jo != qi) {
                 double f[3];
-#ifdef KNN_LAB_NO_PAIR
-                f[0] = (double)jo * 1e-9; f[1] = 0.1; f[2] = 0.2;
-#else
                 pair_features_d(q, qn, acc.pt(j), normals[jo], f);
-#endif
                 atomicAdd(&hist[clamp_bin11((int)floor(11 * (f[0] + M_PI) / (2.0 * M_PI)))], 1);
                 atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
                 atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
