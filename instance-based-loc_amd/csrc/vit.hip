@@ -766,12 +766,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf0, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf1, a, 0, 0, 0);
+            // raw scores: the softmax scale is folded into the exponent below (scale > 0: the maximum commutes); only a tile that
+            // reaches past T needs the key mask (the softmax arithmetic, not the MFMAs, bounds this kernel: ~10 VALU per score before)
+            if (t * 16 + 16 > T) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * 16 + fg * 4 + r;
-                a[r] = key < T ? a[r] * scale : -INFINITY;
-                mx = fmaxf(mx, a[r]);
+                for (int r = 0; r < 4; ++r)
+                    if (t * 16 + fg * 4 + r >= T) a[r] = -INFINITY;
             }
+            mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
             sc[t] = a;
             // keep the K fragments of later tiles from being hoisted up here: unrolled, the 34 ds_read_b128 of a query tile were
             // all issued first (398 VGPRs -> one block per CU); with two blocks per CU the other block hides this latency
@@ -780,11 +782,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
+        const float c2 = scale * 1.4426950408889634f, mc = -mx * c2;       // exp(scale (s - mx)) = exp2(s c2 - mx c2)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[t][r] - mx);
+                const float p = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c2, mc));
                 sc[t][r] = p;
                 sum += p;
             }
