@@ -767,13 +767,13 @@ __global__ void ibl_icp_init_kernel(IcpState* __restrict__ st, int J, const Rans
 // close), after which the other rows are skipped unless their distance lower bound can still reach the best -- a row is
 // only skipped when the bound is strictly larger, so equal distances are always compared by index and the result does
 // not depend on the scan order.
-__device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, float r2,
+// `best` / `*d2out` carry the minimum so far in and out (-1 / r2 to start): a target side is searched piece by piece.
+__device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, int best,
                                          float* d2out) {
     int reach = (int)ceilf(radius * sg.inv);
     if (reach < 1) reach = 1;
     const int cx = (int)floorf((qx - sg.minx) * sg.inv), cy = (int)floorf((qy - sg.miny) * sg.inv), cz = (int)floorf((qz - sg.minz) * sg.inv);
-    int best = -1;
-    float bd = r2;
+    float bd = *d2out;
     const int x0 = max(cx - reach, 0), x1 = min(cx + reach, sg.nx - 1);
     const float csz = 1.0f / sg.inv, slack = 1e-4f * csz + 1e-6f;
     auto scan_row = [&](int z, int y) {
@@ -817,9 +817,12 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
 // Thread per source point of every job: nearest target point under the job's current T.  Split from the accumulation so
 // that this latency-bound neighbour walk runs with few registers (many waves per SIMD hide the dependent cell / point
 // loads) while the fp64 normal equations run in their own kernel on coalesced inputs.
+// The grid has one segment per source side (0 .. J) and one per target INSTANCE (J + 3 j + t, `piece_off`): a side made of instances far
+// apart would otherwise get one coarse grid over their union (>= extent / 128 per cell, hundreds of points per cell: one such job
+// quadrupled the ICP time of its batch).
 __global__ __launch_bounds__(256) void ibl_icp_nn_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ job_off, int J,
-                                                         const IcpState* __restrict__ st, float radius, float r2, int* __restrict__ nn_idx,
-                                                         float* __restrict__ nn_d2) {
+                                                         const int* __restrict__ piece_off, const IcpState* __restrict__ st, float radius,
+                                                         float r2, int* __restrict__ nn_idx, float* __restrict__ nn_d2) {
     const int ns = job_off[J];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ns) return;
@@ -833,8 +836,14 @@ __global__ __launch_bounds__(256) void ibl_icp_nn_kernel(BatchGrid g, const floa
     double T[12], vs[3];
     for (int t = 0; t < 12; ++t) T[t] = S.T[t];
     xform_d(T, s4.x, s4.y, s4.z, vs);
-    float d2;
-    nn_idx[i] = nn_within(g, g.seg[J + j], (float)vs[0], (float)vs[1], (float)vs[2], radius, r2, &d2);
+    float d2 = r2;
+    int best = -1;
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {
+        const int k = J + 3 * j + t;
+        if (piece_off[k + 1] > piece_off[k]) best = nn_within(g, g.seg[k], (float)vs[0], (float)vs[1], (float)vs[2], radius, best, &d2);
+    }
+    nn_idx[i] = best;
     nn_d2[i] = d2;
 }
 
@@ -1101,6 +1110,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     // (radius 2 * max_dist, reach 2); grid A (cell = normal radius) only serves the normals
     phase("job assembly");
     BatchGrid gC;
+    int* d_piece_off = nullptr;
     {
         // With the instance boxes on the host (instance features carry them) the table is sized from an upper bound of every job
         // side's extent -- centring moves a side, it does not stretch it beyond rounding -- and the build needs no read-back.
@@ -1111,14 +1121,15 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         float cellC = (float)(max_dist_icp / ICP_CELL_DIV);
         auto bound_for = [&](float cell0) -> int64_t {
             int64_t bound = 0;
-            for (int sgi = 0; sgi < 2 * J; ++sgi) {
-                const int pl = sgi >= J ? 1 : 0, j = pl ? sgi - J : sgi;
+            for (int sgi = 0; sgi < 4 * J; ++sgi) {
+                const int pl = sgi >= J ? 1 : 0, j = pl ? (sgi - J) / 3 : sgi, only = pl ? (sgi - J) % 3 : -1;
                 const int* segs = pl ? jobs[j].tgt_seg : jobs[j].src_seg;
                 const int* off = pl ? mem_off_host : det_off_host;
                 const float* boxes = pl ? mem_features->bbox : det_features->bbox;
                 float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
                 bool any = false;
                 for (int t = 0; t < 3; ++t) {
+                    if (only >= 0 && t != only) continue;
                     if (segs[t] < 0 || off[segs[t] + 1] == off[segs[t]]) continue;
                     const float* b = boxes + 6 * (size_t)segs[t];
                     for (int c = 0; c < 3; ++c) { lo[c] = any ? std::min(lo[c], b[c]) : b[c]; hi[c] = any ? std::max(hi[c], b[3 + c]) : b[3 + c]; }
@@ -1133,13 +1144,24 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             }
             return bound;
         };
+        // segments of this grid: the J source sides, then every target side instance by instance
+        std::vector<int> piece_off(4 * (size_t)J + 1, 0);
+        for (int j = 0; j <= J; ++j) piece_off[j] = job_off[j];
+        for (int j = 0; j < J; ++j)
+            for (int t = 0; t < 3; ++t) {
+                const int b = jobs[j].tgt_seg[t];
+                piece_off[J + 3 * j + t + 1] = piece_off[J + 3 * j + t] + (b >= 0 ? mem_off_host[b + 1] - mem_off_host[b] : 0);
+            }
+        IBL_ARENA(d_piece_off, int, 4 * (int64_t)J + 1);
+        st = ibl_stage_upload(ctx, d_piece_off, piece_off.data(), sizeof(int) * (4 * (int64_t)J + 1), s);
+        if (st) return st;
         int64_t bound = have ? bound_for(cellC) : 0;
         for (int tries = 0; have && bound >= budget && tries < 12; ++tries) { cellC *= 1.5f; bound = bound_for(cellC); }
         if (have && bound < budget) {
-            st = ibl_build_batch_grid_bounded(ctx, P, d_job_off, job_off.data(), 2 * J, cellC, bound, &gC, s);
+            st = ibl_build_batch_grid_bounded(ctx, P, d_piece_off, piece_off.data(), 4 * J, cellC, bound, &gC, s);
         } else {
             for (int tries = 0; tries < 8; ++tries) {
-                st = ibl_build_batch_grid(ctx, P, d_job_off, job_off.data(), 2 * J, cellC, budget, &gC, s);
+                st = ibl_build_batch_grid(ctx, P, d_piece_off, piece_off.data(), 4 * J, cellC, budget, &gC, s);
                 if (st != IBL_ERR_OVERFLOW) break;
                 cellC *= 2.0f;
             }
@@ -1541,14 +1563,20 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 const int nblk = round_size / 256;
                 const int n_tab = n_act * nblk;           // tables are indexed by (slot in the active list, block)
                 IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_act * round_size, s));
-                if (round_size >= 16384)
-                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<16>, dim3(round_size / 16384, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
-                                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
-                                       blk_cnt, active);
-                else
-                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<4>, dim3(round_size / 4096, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
-                                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
-                                       blk_cnt, active);
+                // hypotheses per block: 16 k (one dense Kabsch pass per block amortises best; 4 k in the first 4 k-round);
+                // the tail rounds of one or two jobs that never reach the confidence exit (1 M hypotheses each) ran on 64 blocks per job
+                // at 16 k -- 18 ms for one job's 4 M hypotheses -- so they take 4 k or 1 k per block instead
+                const long long blocks16 = (long long)(round_size / 16384) * n_act;
+                const long long blocks4 = (long long)(round_size / 4096) * n_act;
+#define IBL_RANSAC_FLAG(SUBS)                                                                                                                     \
+    hipLaunchKernelGGL(ibl_ransac_flag_kernel<SUBS>, dim3(round_size / (1024 * SUBS), n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,      \
+                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags, blk_cnt, \
+                       active)
+                const bool tail = round_size == RANSAC_TAIL_ROUND;
+                if (round_size >= 16384 && (!tail || blocks16 >= 2048)) IBL_RANSAC_FLAG(16);
+                else if (!tail || blocks4 >= 2048) IBL_RANSAC_FLAG(4);
+                else IBL_RANSAC_FLAG(1);
+#undef IBL_RANSAC_FLAG
                 IBL_LAUNCH_CHECK();
                 IBL_HIP_CHECK(hipMemsetAsync(blk_cnt + n_tab, 0, sizeof(int), s));
                 IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, n_tab + 1, s));
@@ -1609,7 +1637,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         const double lambda_geometric = 0.968;
         const int max_iter = 30;
         for (int it = 0; it <= max_iter; ++it) {
-            hipLaunchKernelGGL(ibl_icp_nn_kernel, dim3((Ns + 255) / 256), dim3(256), 0, s, gC, P, d_job_off, J, is, (float)max_dist_icp,
+            hipLaunchKernelGGL(ibl_icp_nn_kernel, dim3((Ns + 255) / 256), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is, (float)max_dist_icp,
                                (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
             IBL_LAUNCH_CHECK();
             hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, P, normals, grad, d_job_off, J, is, icp_nn, icp_d2,
