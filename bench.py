@@ -346,7 +346,7 @@ def main():
     roof_iso = None
     if not args.sequential:                               # per-stage device times of one step run back to back, outside the timed region
         # (averaged over up to four different batches: a batch with a job that never reaches RANSAC's confidence exit walks all 4 M
-        # hypotheses and doubles its "register" time -- one such batch is not the typical step)
+        # hypotheses, or whose targets lie far apart, can double its "register" time -- one such batch is not the typical step)
         n_extra = max(1, min(4, args.steps))
         prof.reset(enable=os.environ.get("IBL_BENCH_NOPROF", "") == "")
         for i in range(n_extra):

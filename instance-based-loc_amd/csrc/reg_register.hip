@@ -1563,20 +1563,14 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 const int nblk = round_size / 256;
                 const int n_tab = n_act * nblk;           // tables are indexed by (slot in the active list, block)
                 IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_act * round_size, s));
-                // hypotheses per block: 16 k (one dense Kabsch pass per block amortises best; 4 k in the first 4 k-round);
-                // the tail rounds of one or two jobs that never reach the confidence exit (1 M hypotheses each) ran on 64 blocks per job
-                // at 16 k -- 18 ms for one job's 4 M hypotheses -- so they take 4 k or 1 k per block instead
-                const long long blocks16 = (long long)(round_size / 16384) * n_act;
-                const long long blocks4 = (long long)(round_size / 4096) * n_act;
-#define IBL_RANSAC_FLAG(SUBS)                                                                                                                     \
-    hipLaunchKernelGGL(ibl_ransac_flag_kernel<SUBS>, dim3(round_size / (1024 * SUBS), n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,      \
-                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags, blk_cnt, \
-                       active)
-                const bool tail = round_size == RANSAC_TAIL_ROUND;
-                if (round_size >= 16384 && (!tail || blocks16 >= 2048)) IBL_RANSAC_FLAG(16);
-                else if (!tail || blocks4 >= 2048) IBL_RANSAC_FLAG(4);
-                else IBL_RANSAC_FLAG(1);
-#undef IBL_RANSAC_FLAG
+                if (round_size >= 16384)
+                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<16>, dim3(round_size / 16384, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
+                                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
+                                       blk_cnt, active);
+                else
+                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<4>, dim3(round_size / 4096, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
+                                       (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
+                                       blk_cnt, active);
                 IBL_LAUNCH_CHECK();
                 IBL_HIP_CHECK(hipMemsetAsync(blk_cnt + n_tab, 0, sizeof(int), s));
                 IBL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, blk_cnt, blk_off, n_tab + 1, s));
