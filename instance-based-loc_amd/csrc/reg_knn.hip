@@ -727,7 +727,7 @@ struct GradConsumer {
 // false -- before any consumer call -- when that cannot be shown or the boundary bin overflows its list; the caller then runs
 // hybrid_select for the query.  Selection rule and tie order (d2 bits, then original index) are those of hybrid_select.
 template <class TL, class Consumer>
-__device__ bool tile_select(const TL& T, int total, const float4 q, float cover2, float r2, int max_nn, WaveLds* L, Consumer& cons) {
+__device__ bool tile_select(const TL& T, int total, const float4 q, float cover2, float r2, int max_nn, WaveLds* L, Consumer& cons, int& gbin) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float bscale = (float)KNN_BINS / r2;
@@ -736,14 +736,28 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
     for (int t = 0; t < KNN_BINS / 64; ++t) L->hist[lane * (KNN_BINS / 64) + t] = 0;
     wave_lds_sync();
     int in_ball = 0;
+    // While the histogram is built, the candidates up to a GUESS of the threshold bin (the previous query of this wave, a neighbour in
+    // the same tile, + 25 %) are parked in the boundary arrays, which are idle until the second pass.  When the guess covers the true
+    // threshold bin and the list did not overflow, the selection below runs over that list (<= 256 entries) instead of all the staged
+    // candidates a second time (~1 200): the same candidates in the same (d2 bits, index) order either way.
+    const int guess = gbin;
+    int ccount = 0;
 #pragma unroll 1
     for (int t0 = 0; t0 < total; t0 += 64) {
         const int t = t0 + lane;
         const float4 p = T.pts[t < total ? t : 0];
         const float d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
         const bool in = t < total && d2 < r2;
-        if (in) atomicAdd(&L->hist[bin_of(d2)], 1);
+        const int b = in ? bin_of(d2) : KNN_BINS;
+        if (in) atomicAdd(&L->hist[b], 1);
         in_ball += __popcll(__ballot(in && d2 < cover2));
+        const bool col = b <= guess;
+        const unsigned long long mc = __ballot(col);
+        if (col) {
+            const int pos = ccount + __popcll(mc & lt_mask);
+            if (pos < KNN_CAPB) { L->b_j[pos] = t; L->b_bits[pos] = __float_as_uint(d2); }
+        }
+        ccount += __popcll(mc);
     }
     wave_lds_sync();
     int hb[KNN_BINS / 64];
@@ -776,10 +790,35 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
         n_below = __shfl(my_below, Lc, 64);
         pop = __shfl(my_pop, Lc, 64);
         if (pop > KNN_CAPB) return false;
+        gbin = min(KNN_BINS - 1, bstar + (bstar >> 2) + 2);
     }
     cons.begin(k);
     int bcount = 0;
     const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool from_list = !select_all && bstar <= guess && ccount <= KNN_CAPB;
+    if (from_list) {
+#pragma unroll 1
+        for (int e0 = 0; e0 < ccount; e0 += 64) {
+            const int e = e0 + lane;
+            const bool v = e < ccount;
+            const int t = v ? L->b_j[e] : 0;
+            const unsigned bits = v ? L->b_bits[e] : 0u;
+            const float d2 = __uint_as_float(bits);
+            const int b = v ? bin_of(d2) : KNN_BINS;
+            cons.accept(b < bstar, t, none, d2);
+            // the boundary bin is compacted in place: a parked entry lands at or before the slot it was read from, and every lane of
+            // this step has read its slot before the first store is issued
+            const bool park = b == bstar;
+            const unsigned long long m = __ballot(park);
+            if (park) {
+                const int pos = bcount + __popcll(m & lt_mask);
+                L->b_bits[pos] = bits;
+                L->b_idx[pos] = T.ord[t];
+                L->b_j[pos] = t;
+            }
+            bcount += __popcll(m);
+        }
+    } else
 #pragma unroll 1
     for (int t0 = 0; t0 < total; t0 += 64) {
         const int t = t0 + lane;
@@ -936,6 +975,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     if (lane == 0) P->n = 0;
     wave_lds_sync();
     const TileAcc tacc{T.pts, T.ord};
+    int gbin = -1;                         // threshold-bin guess carried from query to query of this wave (-1: none yet)
     int run_r = 0;
     for (int qk = wave; qk < nq; qk += 4) {
         while (qk >= T.q_off[run_r + 1]) ++run_r;
@@ -949,7 +989,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
             if (cover < 0.f) cover = 0.f;
             const float cover2 = cover >= radius ? INFINITY : cover * cover;
             auto cons = fac.template make<TileAcc>(qi, q, L, tacc, P);
-            done = tile_select(T, total, q, cover2, r2, max_nn, L, cons);
+            done = tile_select(T, total, q, cover2, r2, max_nn, L, cons, gbin);
         }
         // not provable from the staged cube (sparse spot, LDS budget, boundary-bin overflow): the query joins the list of the
         // per-query grid walk that runs after this kernel (ibl_knn_list_kernel)
