@@ -1142,20 +1142,9 @@ __device__ __forceinline__ float spfh_value(const unsigned char* __restrict__ sp
 // the lanes then switch roles to "one histogram bin each" and walk the tile.  The sum over neighbours keeps the list order.
 struct FpfhTile {
     unsigned char cnt[64][36];
-    double inc[64];       // 100 / (k_j - 1), or 0 when the neighbour has no SPFH
-    double dist[64];      // d2; <= 0 marks a skipped entry (self or zero distance)
-    double rcp[64];       // RN(1 / d2), one IEEE division per neighbour instead of one per (neighbour, bin)
+    double w[64];         // (100 / (k_j - 1)) / d2: the weight of the neighbour's integer histogram; 0 for a skipped entry (the point
+                          // itself, zero distance, a neighbour without SPFH)
 };
-
-// RN(x / d) from y = RN(1 / d): q <- q + (x - q d) y twice (Markstein 1990: with a correctly rounded reciprocal and a
-// faithful q the correction yields the correctly rounded quotient; the first step makes q faithful, the second applies the
-// theorem).  d is a float's square distance (24 significant bits), so the theorem's all-ones-mantissa exception cannot occur;
-// x and d are far from the under/overflow ranges.  5 fp64 operations instead of the ~12 of the division expansion.
-__device__ __forceinline__ double div_by_rcp(double x, double d, double y) {
-    const double q0 = x * y;
-    const double q1 = fma(fma(-q0, d, x), y, q0);
-    return fma(fma(-q1, d, x), y, q1);
-}
 
 // A workgroup serves FPFH_Q = 7 points: thread p < 231 owns (point p / 33, bin p % 33), so 231 of its 256 lanes work (one wave per
 // point left 31 of 64 idle in the loop below, which is the whole kernel).  Neighbour rows are staged 64 per point at a time; each
@@ -1191,24 +1180,16 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
                 unsigned int* dst = reinterpret_cast<unsigned int*>(S.cnt[r]);
 #pragma unroll
                 for (int w = 0; w < 9; ++w) dst[w] = src[w];
-                S.inc[r] = kj > 1 ? 100.0 / (double)(kj - 1) : 0.0;
-                const bool skip = j == si || dist == 0.0;
-                S.dist[r] = skip ? -1.0 : dist;
-                S.rcp[r] = skip ? 0.0 : 1.0 / dist;
+                // SPFH(j)[b] / d2 = count x (increment / d2) in double (Open3D keeps its histograms in double; oracle_fpfh likewise): one
+                // division per neighbour, one fma per (neighbour, bin); a zero weight or an empty bin adds an exact zero
+                S.w[r] = (j == si || dist == 0.0 || kj <= 1) ? 0.0 : (100.0 / (double)(kj - 1)) / dist;
             }
         }
         __syncthreads();
         if (mine && k > 1) {
             const FpfhTile& T = tiles[qq];
             const int m = min(64, k - t0);
-            for (int r = 0; r < m; ++r) {
-                const double dist = T.dist[r];
-                if (dist <= 0.0) continue;
-                const unsigned cb = T.cnt[r][b];
-                if (cb == 0) continue;                        // an empty bin adds an exact zero
-                const float sp = (float)((double)cb * T.inc[r]);
-                acc += div_by_rcp((double)sp, dist, T.rcp[r]);
-            }
+            for (int r = 0; r < m; ++r) acc = fma((double)T.cnt[r][b], T.w[r], acc);
         }
         __syncthreads();
     }

@@ -325,6 +325,8 @@ void oracle_fpfh(const float* pts, const float* normals, int n, double radius, i
     grid_build(&g, pts, n, (float)radius);
     const float r2 = (float)(radius * radius);
     float* spfh = (float*)calloc((size_t)n * 33 + 1, sizeof(float));
+    unsigned char* cnt = (unsigned char*)calloc((size_t)n * 33 + 1, 1);      /* the integer SPFH histograms (<= max_nn - 1 per bin) */
+    double* incs = (double*)calloc((size_t)n + 1, sizeof(double));           /* 100 / (k - 1) */
     int* nbr = (int*)malloc(sizeof(int) * (size_t)n * (size_t)max_nn + 4);
     float* nd2 = (float*)malloc(sizeof(float) * (size_t)n * (size_t)max_nn + 4);
     int* ncnt = (int*)malloc(sizeof(int) * (size_t)n + 4);
@@ -348,7 +350,8 @@ void oracle_fpfh(const float* pts, const float* normals, int n, double radius, i
                     hist[22 + clamp_bin((int)floor(11 * (f[2] + 1.0) * 0.5))]++;
                 }
                 double inc = 100.0 / (double)(k - 1);
-                for (int b = 0; b < 33; ++b) spfh[(size_t)i * 33 + b] = (float)(hist[b] * inc);
+                incs[i] = inc;
+                for (int b = 0; b < 33; ++b) { spfh[(size_t)i * 33 + b] = (float)(hist[b] * inc); cnt[(size_t)i * 33 + b] = (unsigned char)hist[b]; }
             }
         }
         free(buf);
@@ -363,8 +366,11 @@ void oracle_fpfh(const float* pts, const float* normals, int n, double radius, i
                 if (j == i) continue;
                 double dist = nd2[(size_t)i * max_nn + t];
                 if (dist == 0.0) continue;
+                /* SPFH(j)[b] / d2 with the neighbour's histogram in double, as Open3D keeps it (Feature::data_ is a MatrixXd): count x
+                 * (increment / d2) -- one division per neighbour; it differs from (count x increment) / d2 by an ulp of double */
+                const double w = incs[j] / dist;
                 for (int b = 0; b < 33; ++b) {
-                    double val = spfh[(size_t)j * 33 + b] / dist;
+                    double val = (double)cnt[(size_t)j * 33 + b] * w;
                     sum[b / 11] += val;
                     acc[b] += val;
                 }
@@ -375,7 +381,7 @@ void oracle_fpfh(const float* pts, const float* normals, int n, double radius, i
             for (int b = 0; b < 33; ++b) fpfh[(size_t)i * 33 + b] = 0.0f;
         }
     }
-    free(spfh); free(nbr); free(nd2); free(ncnt);
+    free(spfh); free(cnt); free(incs); free(nbr); free(nd2); free(ncnt);
     grid_free(&g);
 }
 
