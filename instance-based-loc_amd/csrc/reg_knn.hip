@@ -582,7 +582,7 @@ __device__ inline void pair_features_d(const float4& p1, const float4& n1f, cons
     double d[3] = {(double)p2.x - (double)p1.x, (double)p2.y - (double)p1.y, (double)p2.z - (double)p1.z};
     double n1[3] = {n1f.x, n1f.y, n1f.z}, n2[3] = {n2f.x, n2f.y, n2f.z};
     const double r = sqrt(dot3d(d, d));
-    f[0] = f[1] = f[2] = 0;
+    f[0] = 5.0; f[1] = f[2] = 0;          // (all-zero features: theta = 0 lies in bin 5; f[0] is a bin index, see below)
     if (r == 0.0) return;
     const double a1 = dot3d(n1, d) / r, a2 = dot3d(n2, d) / r;
     double na[3], nb[3];
@@ -597,11 +597,33 @@ __device__ inline void pair_features_d(const float4& p1, const float4& n1f, cons
     double v[3], w[3];
     cross3d(d, na, v);
     const double vn = sqrt(dot3d(v, v));
-    if (vn == 0.0) { f[0] = f[1] = f[2] = 0; return; }
+    if (vn == 0.0) { f[0] = 5.0; f[1] = f[2] = 0; return; }
     v[0] /= vn; v[1] /= vn; v[2] /= vn;
     cross3d(na, v, w);
     f[1] = dot3d(v, nb);
-    f[0] = atan2(dot3d(w, nb), dot3d(na, nb));
+    // f[0] carries the BIN of theta = atan2(w.nb, na.nb), floor(11 (theta + pi) / (2 pi)), found without the arctangent (~120 fp64
+    // instructions): theta' = theta + pi is the angle of p = (-x, -y), and within a half plane "theta' >= 2 pi k / 11" is the sign of the
+    // cross product with the boundary direction -- five tests.  The half plane follows atan2's sign-of-zero rule (y = +0, x < 0 is
+    // +pi -> last bin; y = -0 is -pi -> bin 0: antiparallel normals on a plane land there).  It can differ from the arctangent only
+    // for an angle within rounding of a boundary.
+    {
+        const double x = dot3d(na, nb), y = dot3d(w, nb);
+        constexpr double CK[10] = {0.84125353283118121, 0.41541501300188644, -0.142314838273285, -0.65486073394528499, -0.95949297361449737, -0.95949297361449748, -0.65486073394528521, -0.14231483827328523, 0.41541501300188605, 0.84125353283118121};
+        constexpr double SK[10] = {0.54064081745559756, 0.90963199535451833, 0.9898214418809328, 0.75574957435425827, 0.28173255684142967, -0.28173255684142939, -0.75574957435425816, -0.98982144188093268, -0.90963199535451855, -0.54064081745559744};
+        const double px = -x, py = -y;
+        int bin;
+        if (!(__double_as_longlong(py) < 0)) {            // py = +0 or positive: theta' in [0, pi]
+            bin = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) bin += (CK[k] * py - SK[k] * px >= 0.0) ? 1 : 0;
+        } else {                                           // theta' in (pi, 2 pi]
+            bin = 5;
+#pragma unroll
+            for (int k = 5; k < 10; ++k) bin += (CK[k] * py - SK[k] * px >= 0.0) ? 1 : 0;
+        }
+        if (x == 0.0 && y == 0.0) bin = (__double_as_longlong(x) < 0) ? ((__double_as_longlong(y) < 0) ? 0 : 10) : 5;   // atan2(+-0, +-0)
+        f[0] = (double)bin;
+    }
 }
 
 __device__ __forceinline__ int clamp_bin11(int h) { return h < 0 ? 0 : (h >= 11 ? 10 : h); }
@@ -649,7 +671,7 @@ struct SpfhConsumer {
             if (jo != qi) {
                 double f[3];
                 pair_features_d(q, qn, acc.pt(j), normals[jo], f);
-                atomicAdd(&hist[clamp_bin11((int)floor(11 * (f[0] + M_PI) / (2.0 * M_PI)))], 1);
+                atomicAdd(&hist[clamp_bin11((int)f[0])], 1);
                 atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
                 atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
             }
