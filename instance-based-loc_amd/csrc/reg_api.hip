@@ -36,6 +36,10 @@ int ibl_launch_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, con
 int ibl_launch_radius_count(const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius, int nb_points,
                             unsigned char* keep, hipStream_t s);
 
+bool ibl_normals_fpfh_fusable(double radius_normal, int max_nn_normal, double radius_feature, int max_nn_feature);
+int ibl_launch_normals_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius_normal,
+                            int max_nn_normal, double radius_feature, int max_nn_feature, float4* normals, unsigned char* spfh, int* nbr_idx,
+                            float* nbr_d2, int* nbr_cnt, float* fpfh, int matching_order, int* status, hipStream_t s);
 int ibl_launch_color_grad(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const float4* normals, const int* seg_off, int q0, int q1, double radius,
                           int max_nn, float4* grad, int* status, hipStream_t s);
 
@@ -133,7 +137,8 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
     std::vector<float> bbox_host((size_t)n_seg * 6 + 6);
     st = ibl_bbox_to_host(ctx, P, seg_off_dev, n_seg, bbox_host.data(), s);
     if (st) return st;
-    {
+    const bool fused = fpfh && radius_feature > 0 && max_nn_feature > 0 && ibl_normals_fpfh_fusable(radius_normal, max_nn_normal, radius_feature, max_nn_feature);
+    if (!fused) {
         ArenaMark m2(ctx);
         BatchGrid g;
         st = ibl_build_tile_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, bbox_host.data(), radius_normal, max_nn_normal, KNN_TILE_NORMAL,
@@ -153,8 +158,12 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
         IBL_ARENA(nbr_idx, int, (int64_t)n * max_nn_feature + 64);
         IBL_ARENA(nbr_d2, float, (int64_t)n * max_nn_feature + 64);
         IBL_ARENA(nbr_cnt, int, n + 64);
-        st = ibl_launch_fpfh(ctx, g, P, reinterpret_cast<const float4*>(normals4), seg_off_dev, n, radius_feature, max_nn_feature, spfh,
-                             nbr_idx, nbr_d2, nbr_cnt, fpfh, 0, ctx->d_status, s);
+        if (fused)           // one search for both (the 30 nearest within the normal radius are among the 100 nearest within the feature radius)
+            st = ibl_launch_normals_fpfh(ctx, g, P, seg_off_dev, n, radius_normal, max_nn_normal, radius_feature, max_nn_feature,
+                                         reinterpret_cast<float4*>(normals4), spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 0, ctx->d_status, s);
+        else
+            st = ibl_launch_fpfh(ctx, g, P, reinterpret_cast<const float4*>(normals4), seg_off_dev, n, radius_feature, max_nn_feature, spfh,
+                                 nbr_idx, nbr_d2, nbr_cnt, fpfh, 0, ctx->d_status, s);
         if (st) return st;
     }
     IBL_HIP_CHECK(hipStreamSynchronize(s));        // the pinned staging of the grid tables is recycled by the next call
@@ -207,7 +216,8 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
         if (st) return st;
         bbox_host = own_bbox.data();
     }
-    {
+    const bool fused = fpfh && ibl_normals_fpfh_fusable(voxel_size * 2, 30, voxel_size * 5, 100);
+    if (!fused) {
         ArenaMark mA(ctx);
         BatchGrid gA;
         st = ibl_build_tile_grid(ctx, P, seg_off_dev, seg_off_host, n_seg, bbox_host, voxel_size * 2, 30, KNN_TILE_NORMAL, (int64_t)128 << 20, &gA, s);
@@ -225,7 +235,9 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
         IBL_ARENA(nbr_idx, int, (int64_t)n * 100 + 64);
         IBL_ARENA(nbr_d2, float, (int64_t)n * 100 + 64);
         IBL_ARENA(nbr_cnt, int, n + 64);
-        st = ibl_launch_fpfh(ctx, gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
+        if (fused) st = ibl_launch_normals_fpfh(ctx, gB, P, seg_off_dev, n, voxel_size * 2, 30, voxel_size * 5, 100, normals, spfh, nbr_idx, nbr_d2, nbr_cnt,
+                                                fpfh, 1, ctx->d_status, s);
+        else st = ibl_launch_fpfh(ctx, gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
         if (st) return st;
         if (fpfh_split && fpfh_norm) {
             hipLaunchKernelGGL(ibl_fpfh_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fpfh, n, fpfh_split, fpfh_norm);

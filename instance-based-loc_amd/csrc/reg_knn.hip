@@ -503,12 +503,15 @@ __device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const Acc& ac
 // The sums run in the same order on every path (tile, list, query kernel), so a point's normal does not depend on which one served it.
 #define NP_SLOTS 16
 #define NP_MAXK 32
-struct NormalPending {
-    unsigned short h[NP_SLOTS][NP_MAXK];
-    int qi[NP_SLOTS];
-    int k[NP_SLOTS];
+template <int SLOTS_>
+struct NormalPendingT {
+    static constexpr int SLOTS = SLOTS_;
+    unsigned short h[SLOTS_][NP_MAXK];
+    int qi[SLOTS_];
+    int k[SLOTS_];
     int n;
 };
+typedef NormalPendingT<NP_SLOTS> NormalPending;
 struct NoPending { int n; };
 
 template <class Acc, class H>
@@ -537,8 +540,8 @@ __device__ __forceinline__ void normal_solve(const Acc& acc, const H* __restrict
     normals[qi] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.0f);
 }
 
-template <class Acc>
-__device__ __forceinline__ void normal_flush(NormalPending* P, const Acc& acc, float4* __restrict__ normals) {
+template <class Acc, class PT>
+__device__ __forceinline__ void normal_flush(PT* P, const Acc& acc, float4* __restrict__ normals) {
     const int lane = threadIdx.x & 63;
     wave_lds_sync();
     const int n = P->n;
@@ -546,6 +549,22 @@ __device__ __forceinline__ void normal_flush(NormalPending* P, const Acc& acc, f
     wave_lds_sync();
     if (lane == 0) P->n = 0;
     wave_lds_sync();
+}
+
+// End of a tile: the queries still parked by the four waves (two or three each -- a tile holds ~10 queries) are solved together by
+// wave 0, one per lane, instead of once per wave with two or three lanes active.
+template <class Acc, class PT>
+__device__ __forceinline__ void normal_flush_block(PT* pend, const Acc& acc, float4* __restrict__ normals) {
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 0) {
+        const int lane = threadIdx.x & 63;
+        const int n0 = pend[0].n, n1 = pend[1].n, n2 = pend[2].n, n3 = pend[3].n;
+        if (lane < n0 + n1 + n2 + n3) {
+            const int w = lane < n0 ? 0 : (lane < n0 + n1 ? 1 : (lane < n0 + n1 + n2 ? 2 : 3));
+            const int sl = lane - (w > 0 ? n0 : 0) - (w > 1 ? n1 : 0) - (w > 2 ? n2 : 0);
+            normal_solve(acc, pend[w].h[sl], pend[w].k[sl], pend[w].qi[sl], normals);
+        }
+    }
 }
 
 template <class Acc>
@@ -681,6 +700,132 @@ struct SpfhConsumer {
         // so the FPFH pass gathers 36 B instead of 132 B per neighbour; the fp32 value is rebuilt on the fly
         if (lane < 36) spfh_cnt[(int64_t)qi * 36 + lane] = lane < 33 ? (unsigned char)hist[lane] : (unsigned char)0;
         if (lane == 0) nbr_cnt[qi] = k;
+    }
+};
+
+// The 100-neighbour search and the normals in one pass (instance features: normal radius <= feature radius, <= 32 normal neighbours):
+// the <= kn nearest of a point within the normal radius are among its k nearest within the feature radius, so the selected list
+// serves both -- the neighbour lists are written for the SPFH / FPFH kernels that follow, and the normal's own neighbours are taken
+// from the list (all entries inside the normal radius, or the kn smallest by (d2 bits, index) through a 64-bin histogram of the
+// list) and parked for the batched solve, in the same ascending-index order as the stand-alone normals kernel: identical normals.
+// This removes that kernel's whole search (2.9 of the 10.8 ms of the two searches per step).
+#define NP_SLOTS_FUSED 8        // 80.9 KiB per workgroup with the 2 560-point tile: two workgroups per CU still fit
+template <class Acc>
+struct ListNormalConsumer {
+    typedef NormalPendingT<NP_SLOTS_FUSED> PT;
+    float4* normals;         // out, original order
+    Acc acc;
+    int* nbr_idx;            // [N][K]
+    float* nbr_d2;           // [N][K]
+    int* nbr_cnt;            // [N]
+    int K;
+    float rn2;               // squared normal radius
+    int kn;                  // normal neighbours (<= NP_MAXK)
+    int qi;
+    WaveLds* L;
+    PT* P;
+    int ncount;
+    __device__ void begin(int) { ncount = 0; }
+    __device__ void accept(bool sel, int j, const float4&, float d2) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int pos = ncount + __popcll(m & ((1ull << lane) - 1ull));
+            L->sel_j[pos] = j;
+            L->sel_d2[pos] = d2;
+        }
+        ncount += __popcll(m);
+    }
+    __device__ void finish(int k) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        sort_selected_by_index<true>(L, acc, k);                  // b_j: handles, b_bits: d2 bits, ascending original index
+        int n_in = 0;
+        for (int t0 = 0; t0 < k; t0 += 64) {
+            const int t = t0 + lane;
+            const bool v = t < k;
+            const unsigned bits = v ? L->b_bits[t] : 0x7F800000u;
+            if (v) {
+                nbr_idx[(int64_t)qi * K + t] = acc.ord(L->b_j[t]);
+                nbr_d2[(int64_t)qi * K + t] = __uint_as_float(bits);
+            }
+            n_in += __popcll(__ballot(v && __uint_as_float(bits) < rn2));
+        }
+        if (lane == 0) nbr_cnt[qi] = k;
+        // ---- the normal's neighbours
+        int b30 = 64, need = 0, popb = 0;
+        const float nscale = 64.0f / rn2;
+        auto nbin = [&](float d2) { const int b = (int)(d2 * nscale); return b > 63 ? 63 : b; };
+        if (n_in > kn) {
+            int* nh = L->scratch;                                   // 64 bins over [0, rn2); free once the index sort is done
+            nh[lane] = 0;
+            wave_lds_sync();
+            for (int t = lane; t < k; t += 64) {
+                const float d2 = __uint_as_float(L->b_bits[t]);
+                if (d2 < rn2) atomicAdd(&nh[nbin(d2)], 1);
+            }
+            wave_lds_sync();
+            const int c = nh[lane];
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            const unsigned long long m = __ballot(incl >= kn);
+            b30 = __ffsll((long long)m) - 1;
+            need = kn - __shfl(incl - c, b30, 64);
+            // the entries of the boundary bin, for the rank by (d2 bits, original index)
+            for (int t0 = 0; t0 < k; t0 += 64) {
+                const int t = t0 + lane;
+                const float d2 = t < k ? __uint_as_float(L->b_bits[t]) : INFINITY;
+                const bool bd = d2 < rn2 && nbin(d2) == b30;
+                const unsigned long long mb = __ballot(bd);
+                if (bd) {
+                    const int pos = popb + __popcll(mb & lt_mask);
+                    L->sel_d2[pos] = d2;
+                    L->sel_j[pos] = t;                               // position in the index-sorted list = index order
+                }
+                popb += __popcll(mb);
+            }
+            wave_lds_sync();
+        }
+        const bool immediate = P == nullptr;
+        const int slot = immediate ? 0 : P->n;
+        int kq = 0;
+        for (int t0 = 0; t0 < k; t0 += 64) {
+            const int t = t0 + lane;
+            const float d2 = t < k ? __uint_as_float(L->b_bits[t]) : INFINITY;
+            bool member = d2 < rn2;
+            if (member && n_in > kn) {
+                const int b = nbin(d2);
+                if (b > b30) member = false;
+                else if (b == b30) {
+                    const unsigned mb = __float_as_uint(d2);
+                    int rank = 0;
+                    for (int u = 0; u < popb; ++u) {
+                        const unsigned ub = __float_as_uint(L->sel_d2[u]);
+                        rank += (ub < mb || (ub == mb && L->sel_j[u] < t)) ? 1 : 0;
+                    }
+                    member = rank < need;
+                }
+            }
+            const unsigned long long mm = __ballot(member);
+            if (member) {
+                const int pos = kq + __popcll(mm & lt_mask);
+                if (immediate) L->b_idx[pos] = L->b_j[t];
+                else P->h[slot][pos] = (unsigned short)L->b_j[t];
+            }
+            kq += __popcll(mm);
+        }
+        if (immediate) {
+            wave_lds_sync();
+            if (lane == 0) normal_solve(acc, L->b_idx, kq, qi, normals);
+        } else {
+            if (lane == 0) { P->qi[slot] = qi; P->k[slot] = kq; P->n = slot + 1; }
+            if (slot + 1 == PT::SLOTS) normal_flush(P, acc, normals);
+            else wave_lds_sync();
+        }
     }
 };
 
@@ -1074,7 +1219,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
         // per-query grid walk that runs after this kernel (ibl_knn_list_kernel)
         if (!done && lane == 0) fb_list[atomicAdd(fb_count, 1)] = jq;
     }
-    fac.flush(P, tacc);                     // the queries still parked (NormalFactory)
+    fac.flush_block(pend, tacc);            // the queries still parked (normals)
 }
 
 struct NormalFactory {
@@ -1086,11 +1231,13 @@ struct NormalFactory {
         return c;
     }
     template <class Acc> __device__ void flush(Pending* P, const Acc& acc) const { normal_flush(P, acc, normals); }
+    template <class Acc> __device__ void flush_block(Pending* pend, const Acc& acc) const { normal_flush_block(pend, acc, normals); }
 };
 struct SpfhFactory {
     typedef NoPending Pending;
     const float4* normals; unsigned char* spfh_cnt; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K;
     template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
+    template <class Acc> __device__ void flush_block(Pending*, const Acc&) const {}
     template <class Acc> __device__ SpfhConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc, Pending* = nullptr) const {
         SpfhConsumer<Acc> c;
         c.normals = normals; c.acc = acc; c.spfh_cnt = spfh_cnt; c.nbr_idx = nbr_idx; c.nbr_d2 = nbr_d2; c.nbr_cnt = nbr_cnt; c.K = K;
@@ -1098,10 +1245,23 @@ struct SpfhFactory {
         return c;
     }
 };
+struct ListNormalFactory {
+    typedef NormalPendingT<NP_SLOTS_FUSED> Pending;
+    float4* normals; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K; float rn2; int kn;
+    template <class Acc> __device__ void flush(Pending* P, const Acc& acc) const { normal_flush(P, acc, normals); }
+    template <class Acc> __device__ void flush_block(Pending* pend, const Acc& acc) const { normal_flush_block(pend, acc, normals); }
+    template <class Acc> __device__ ListNormalConsumer<Acc> make(int qi, const float4&, WaveLds* L, const Acc& acc, Pending* P = nullptr) const {
+        ListNormalConsumer<Acc> c;
+        c.normals = normals; c.acc = acc; c.nbr_idx = nbr_idx; c.nbr_d2 = nbr_d2; c.nbr_cnt = nbr_cnt; c.K = K; c.rn2 = rn2; c.kn = kn;
+        c.qi = qi; c.L = L; c.P = P; c.ncount = 0;
+        return c;
+    }
+};
 struct GradFactory {
     typedef NoPending Pending;
     const float4* normals; float4* grad;
     template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
+    template <class Acc> __device__ void flush_block(Pending*, const Acc&) const {}
     template <class Acc> __device__ GradConsumer<Acc> make(int qi, const float4& q, WaveLds* L, const Acc& acc, Pending* = nullptr) const {
         GradConsumer<Acc> c;
         c.normals = normals; c.acc = acc; c.grad = grad; c.qi = qi; c.q = q; c.qn = normals[qi]; c.L = L; c.ncount = 0;
@@ -1327,6 +1487,59 @@ int ibl_launch_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, con
     if (st) return st;
     hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + FPFH_Q - 1) / FPFH_Q), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn, n, matching_order, fpfh);
     IBL_LAUNCH_CHECK();
+    return IBL_OK;
+}
+
+// SPFH histograms from stored neighbour lists (after the fused search above has written lists and normals): wave per point
+__global__ __launch_bounds__(256) void ibl_spfh_lists_kernel(const float4* __restrict__ pts, const float4* __restrict__ normals,
+                                                             const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt, int K, int n,
+                                                             unsigned char* __restrict__ spfh_cnt) {
+    __shared__ int hists[4][36];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    int* hist = hists[wave];
+    if (lane < 36) hist[lane] = 0;
+    wave_lds_sync();
+    const int k = nbr_cnt[qi];
+    const float4 q = pts[qi], qn = normals[qi];
+    for (int t = lane; t < k; t += 64) {
+        const int jo = nbr_idx[(int64_t)qi * K + t];
+        if (jo != qi) {
+            double f[3];
+            pair_features_d(q, qn, pts[jo], normals[jo], f);
+            atomicAdd(&hist[clamp_bin11((int)f[0])], 1);
+            atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
+            atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
+        }
+    }
+    wave_lds_sync();
+    if (lane < 36) spfh_cnt[(int64_t)qi * 36 + lane] = lane < 33 ? (unsigned char)hist[lane] : (unsigned char)0;
+}
+
+// normals + FPFH from ONE neighbour search (requires radius_normal <= radius_feature, max_nn_normal <= max_nn_feature and <= NP_MAXK)
+bool ibl_normals_fpfh_fusable(double radius_normal, int max_nn_normal, double radius_feature, int max_nn_feature) {
+    const char* e = getenv("IBL_FEAT_UNFUSED");          // diagnostics: 1 = the two separate searches (read per call: the tests compare both)
+    const bool off = e && atoi(e);
+    return !off && radius_normal <= radius_feature && max_nn_normal <= max_nn_feature && max_nn_normal <= NP_MAXK && max_nn_feature <= 256;
+}
+int ibl_launch_normals_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius_normal,
+                            int max_nn_normal, double radius_feature, int max_nn_feature, float4* normals, unsigned char* spfh, int* nbr_idx,
+                            float* nbr_d2, int* nbr_cnt, float* fpfh, int matching_order, int* status, hipStream_t s) {
+    if (n <= 0) return IBL_OK;
+    void* tok;
+    ibl_prof_begin(IBL_PROF_SPFH, 156.0 * (double)n, s, &tok);
+    const int st = launch_knn(ctx, g, pts, seg_off, n, 0, n, radius_feature, max_nn_feature,
+                              ListNormalFactory{normals, nbr_idx, nbr_d2, nbr_cnt, max_nn_feature, (float)(radius_normal * radius_normal), max_nn_normal},
+                              status, s);
+    ibl_prof_end(tok, s);
+    if (st) return st;
+    hipLaunchKernelGGL(ibl_spfh_lists_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pts, normals, nbr_idx, nbr_cnt, max_nn_feature, n, spfh);
+    IBL_LAUNCH_CHECK();
+    if (fpfh) {
+        hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + FPFH_Q - 1) / FPFH_Q), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn_feature, n, matching_order, fpfh);
+        IBL_LAUNCH_CHECK();
+    }
     return IBL_OK;
 }
 

@@ -80,3 +80,22 @@ def test_knn_slow_path_matches_fast_path(ctx):
     ef = ro.fpfh(pts, en, 0.25, 100)
     assert np.mean(np.abs(nrm.cpu().numpy()[:, :3] - en).max(1) < 1e-5) > 0.99
     assert np.mean(np.abs(fpfh.cpu().numpy() - ef).max(1) < 2e-3) > 0.99
+
+
+def test_fused_normals_and_feature_search_equals_the_two_searches(ctx, monkeypatch):
+    """instance features take the normals' <= 30 neighbours from the 100-neighbour list of the feature search (one search instead of two);
+    IBL_FEAT_UNFUSED=1 runs the two stand-alone searches: normals and FPFH must agree bit for bit, dense and sparse clouds alike"""
+    from ibloc_amd.registration import CloudBatch, instance_features_batch, normals_fpfh_batch
+    rng = np.random.default_rng(77)
+    cs = clouds([5000, 1200, 40, 3, 0], 9)
+    cs.append((rng.uniform(-0.05, 0.05, size=(3000, 3))).astype(np.float32))          # > 100 points inside every normal radius
+    b = CloudBatch.from_numpy(cs)
+    got = instance_features_batch(ctx, b, 0.05)
+    n1, f1 = normals_fpfh_batch(ctx, b, 0.1, 30, 0.25, 100)
+    monkeypatch.setenv("IBL_FEAT_UNFUSED", "1")
+    ref = instance_features_batch(ctx, b, 0.05)
+    n2, f2 = normals_fpfh_batch(ctx, b, 0.1, 30, 0.25, 100)
+    torch.cuda.synchronize()
+    assert ctx.status() == 0
+    assert torch.equal(got.normals[:b.n], ref.normals[:b.n]) and torch.equal(got.fpfh[:b.n], ref.fpfh[:b.n])
+    assert torch.equal(n1, n2) and torch.equal(f1, f2)
