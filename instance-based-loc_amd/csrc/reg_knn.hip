@@ -915,10 +915,12 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
     // candidates a second time (~1 200): the same candidates in the same (d2 bits, index) order either way.
     const int guess = gbin;
     int ccount = 0;
+    float4 pnext = T.pts[lane < total ? lane : 0];        // one step ahead: two waves per SIMD do not hide the LDS round trip
 #pragma unroll 1
     for (int t0 = 0; t0 < total; t0 += 64) {
         const int t = t0 + lane;
-        const float4 p = T.pts[t < total ? t : 0];
+        const float4 p = pnext;
+        if (t0 + 64 < total) pnext = T.pts[t + 64 < total ? t + 64 : 0];
         const float d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
         const bool in = t < total && d2 < r2;
         const int b = in ? bin_of(d2) : KNN_BINS;
