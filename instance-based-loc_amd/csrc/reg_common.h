@@ -24,6 +24,7 @@ struct BatchGrid {
     int n_seg;
     // tiles (ibl_build_tile_grid only): cubes of ts^3 cells, one workgroup each in the LDS-staged k-NN kernels (reg_knn.hip)
     const int* tile_base;      // [S + 1] first tile of every segment, or null
+    const int* tile_seg;       // [n_tiles] segment of every tile (a lookup instead of a binary search over tile_base), or null
     int n_tiles;
     int ts;
 };

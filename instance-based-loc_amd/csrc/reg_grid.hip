@@ -192,7 +192,7 @@ int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off
     IBL_ARENA(seg, SegGrid, n_seg + 1);
     IBL_ARENA(total, int, 4);
     out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
-    out->tile_base = nullptr; out->n_tiles = 0; out->ts = 0;
+    out->tile_base = nullptr; out->tile_seg = nullptr; out->n_tiles = 0; out->ts = 0;
     if (n_seg == 0) return IBL_OK;
     hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox);
     IBL_LAUNCH_CHECK();
@@ -214,7 +214,7 @@ int ibl_build_batch_grid_bounded(ibl_reg_ctx* ctx, const float4* pts, const int*
     IBL_ARENA(seg, SegGrid, n_seg + 1);
     IBL_ARENA(total, int, 4);
     out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
-    out->tile_base = nullptr; out->n_tiles = 0; out->ts = 0;
+    out->tile_base = nullptr; out->tile_seg = nullptr; out->n_tiles = 0; out->ts = 0;
     if (n_seg == 0) return IBL_OK;
     if (cells_bound <= 0 || cells_bound > 0x7fff0000ll) return ibl_set_error(IBL_ERR_OVERFLOW, "grid: cell bound %lld out of range", (long long)cells_bound);
     hipLaunchKernelGGL(ibl_bbox_kernel, dim3(n_seg), dim3(256), 0, s, pts, seg_off_dev, bbox);
@@ -248,6 +248,13 @@ int ibl_stage_upload(ibl_reg_ctx* ctx, void* dst_dev, const void* src_host, int6
     return IBL_OK;
 }
 
+// tile -> segment table: a workgroup of the tile search found its segment by a binary search over tile_base, eight dependent loads
+// before it could do anything else
+__global__ __launch_bounds__(256) void ibl_tile_seg_kernel(const int* __restrict__ tile_base, int* __restrict__ tile_seg) {
+    const int sgi = blockIdx.x;
+    for (int t = tile_base[sgi] + threadIdx.x; t < tile_base[sgi + 1]; t += 256) tile_seg[t] = sgi;
+}
+
 int ibl_build_tile_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,
                         const float* bbox_host, double radius, int max_nn, int ts, int64_t max_cells, BatchGrid* out, hipStream_t s) {
     const int n = seg_off_host[n_seg];
@@ -255,7 +262,7 @@ int ibl_build_tile_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_
     IBL_ARENA(seg, SegGrid, n_seg + 1);
     IBL_ARENA(tile_base, int, n_seg + 2);
     out->seg = seg; out->cell_start = nullptr; out->sorted_pts = nullptr; out->order = nullptr; out->n_seg = n_seg;
-    out->tile_base = tile_base; out->n_tiles = 0; out->ts = ts;
+    out->tile_base = tile_base; out->tile_seg = nullptr; out->n_tiles = 0; out->ts = ts;
     if (n_seg == 0) return IBL_OK;
     std::vector<SegGrid> h(n_seg);
     std::vector<int> tb(n_seg + 1, 0);
@@ -297,5 +304,12 @@ int ibl_build_tile_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_
     if (st) return st;
     st = ibl_stage_upload(ctx, tile_base, tb.data(), sizeof(int) * (int64_t)(n_seg + 1), s);
     if (st) return st;
+    if (tiles > 0) {
+        int* tile_seg;
+        IBL_ARENA(tile_seg, int, tiles + 1);
+        hipLaunchKernelGGL(ibl_tile_seg_kernel, dim3(n_seg), dim3(256), 0, s, tile_base, tile_seg);
+        IBL_LAUNCH_CHECK();
+        out->tile_seg = tile_seg;
+    }
     return grid_fill(ctx, pts, seg_off_dev, n_seg, n, seg, (int)cells, out, s);
 }

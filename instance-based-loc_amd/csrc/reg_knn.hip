@@ -1055,10 +1055,12 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     const int tile = blockIdx.x;
     if (tile >= g.n_tiles) return;
     int lo = 0, hi = g.n_seg;                      // the segment whose tile range holds `tile`
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (g.tile_base[mid] <= tile) lo = mid; else hi = mid;
-    }
+    if (g.tile_seg) lo = g.tile_seg[tile];
+    else
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (g.tile_base[mid] <= tile) lo = mid; else hi = mid;
+        }
     const SegGrid sg = g.seg[lo];
     const int ntx = (sg.nx + TS - 1) / TS, nty = (sg.ny + TS - 1) / TS;
     int tt = tile - g.tile_base[lo];
