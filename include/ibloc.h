@@ -318,7 +318,9 @@ int ibl_radius_outlier_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t*
 /* Normals (hybrid radius_normal / max_nn_normal, Open3D fast 3x3 eigen solver, no orientation) and
  * FPFH (hybrid radius_feature / max_nn_feature) of every cloud of the batch.  Replaces
  * downsample_and_compute_fpfh (utils/fpfh_register.py:86-98).  normals4: [dev] N x float4,
- * fpfh: [dev] N x 33 fp32 (point-major) or NULL to skip the features. */
+ * fpfh: [dev] N x 33 fp32 (point-major) or NULL to skip the features.  When radius_normal <= radius_feature and max_nn_normal <=
+ * min(max_nn_feature, 32) -- the reference's 2 / 5 voxel, 30 / 100 neighbours -- ONE neighbour search serves both (the normal's
+ * neighbours are among the feature neighbours); the results are those of the two searches bit for bit (IBL_FEAT_UNFUSED=1 runs them). */
 int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
                            int n_seg, double radius_normal, int max_nn_normal, double radius_feature, int max_nn_feature,
                            float* normals4, float* fpfh, void* stream);
