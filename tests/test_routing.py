@@ -29,6 +29,22 @@ def test_plan_routes_rules():
     assert set(plan.det_send) == {(0, 1), (1, 0)} and set(plan.inst_send) == {(1, 0), (0, 1)}
 
 
+def test_plan_routes_edge_cases():
+    from ibloc_amd.routing import plan_routes
+    M, W = 9, 3                                            # ranks own 0-2, 3-5, 6-8
+    none = np.zeros((0, 3), np.int64)
+    # rank 1 has no jobs at all; rank 0 has a job without targets (stays home, moves nothing) and two jobs sharing a remote segment
+    src0 = [[0, -1, -1], [1, 2, -1], [2, 1, -1]]
+    tgt0 = [[-1, -1, -1], [7, 8, -1], [6, -1, -1]]
+    src2 = [[0, 1, 2]]
+    tgt2 = [[0, 4, 8]]                                     # three owners: runs at home (rank 2), fetches 0 from rank 0 and 4 from rank 1
+    plan = plan_routes([src0, none, src2], [tgt0, none, tgt2], M, W)
+    assert plan.executor[0].tolist() == [0, 2, 2] and len(plan.executor[1]) == 0 and plan.executor[2].tolist() == [2]
+    assert plan.det_send == {} or set(plan.det_send) == {(0, 2)}
+    assert plan.det_send[(0, 2)].tolist() == [1, 2]        # segments 1 and 2 once, although two jobs use them
+    assert {k: v.tolist() for k, v in plan.inst_send.items()} == {(0, 2): [0], (1, 2): [4]}
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["IBL_ROOT"])
