@@ -16,13 +16,15 @@ registered; --sequential runs them back to back); all work of the K timed steps 
 seeded random-init weights (no datasets / checkpoints offline).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            # starts N ranks itself (child `python -m torch.distributed.run`, before any HIP call here)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W [--shard-memory]
+        bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: query frames are independent (tum_localisation_trial.py:215 has no cross-frame state), so each rank localises its own
-frames against a replicated memory -- no data-path collective, "scaling": "weak".  --shard-memory additionally shards the
-embedding memory by instance range: every rank matches all ranks' query rows against its range and the per-shard two-ended
-candidate lists are all-gathered over RCCL before the assignment search.
+Multi-GPU (one process per GPU, "scaling": "weak": every rank localises --frames frames per step).  Default layout at N > 1 is the
+north star's: the embedding memory is sharded by instance range (`--layout sharded`), every rank matches all ranks' query rows against
+its range and the per-shard two-ended top-k candidate lists are exchanged over the library's RCCL communicator before the assignment
+search; clouds, resident features and the evaluation grid stay replicated while they fit 288 GB (--shard-clouds shards
+them too).  `--layout replicated` is the communication-free alternative (frames are independent, tum_localisation_trial.py:215).
 """
 import argparse
 import json
@@ -121,7 +123,7 @@ def build_workload(args, rank, world_size, device):
     t0 = time.time()
     enc, dim = make_encoder(args.model, device)
     world = SynthWorld(args.memory, pts_per_object=max(args.points, 16), E=args.views, D=dim, seed=21,
-                       sample_points=args.register)
+                       sample_points=args.register, spacing=args.spacing)
     rng = np.random.default_rng(21)
     crops = Crops(args.model, 21)
     # query batches first (distinct per step and per rank): they tell which instances are ever looked at
@@ -244,6 +246,30 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
     return n_frames / dt, dt, threads
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (this process has
+    made no HIP call and never will: a process that initialised the GPU must not exec or fork GPU work), relay their output -- rank 0
+    prints the JSON line -- and exit with the child's code, so a failed rank fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc != 0:
+        print(f"[bench] the {n}-rank run failed (exit code {rc})", file=sys.stderr)
+    sys.exit(rc)
+
+
 def rot_err(R_est, R_gt):
     c = (np.trace(R_est.T @ R_gt) - 1.0) / 2.0
     return float(np.arccos(np.clip(c, -1.0, 1.0)))
@@ -270,9 +296,17 @@ def main():
                     "(per-shard candidate top-k + RCCL all-gather) instead of replicating it")
     ap.add_argument("--shard-clouds", action="store_true", help="also shard the memory clouds by instance range: registration jobs run at "
                     "the owner of their targets or fetch the instances they miss, whole-memory evaluation is reduced over the ranks")
-    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"], help="transport of the --shard-memory collectives: "
-                    "torch.distributed's nccl (= RCCL) group, or the library's own RCCL communicator (ibl_comm_*)")
+    ap.add_argument("--comm", default=None, choices=["torch", "rccl"], help="transport of the sharded layout's collectives: "
+                    "torch.distributed's nccl (= RCCL) group, or the library's own RCCL communicator (ibl_comm_*; default)")
+    ap.add_argument("--layout", default="auto", choices=["auto", "sharded", "replicated"],
+                    help="N > 1: `sharded` (default) = embedding memory sharded by instance range + RCCL exchange of the per-shard top-k "
+                    "candidate lists (north star); `replicated` = every rank holds the whole memory, no data-path collective")
+    ap.add_argument("--spacing", type=float, default=2.5, help="grid spacing of the synthetic memory's objects in metres (2.5: separated "
+                    "objects; ~0.7: adjacent objects whose neighbourhoods overlap, so cross-instance features are recomputed)")
+    ap.add_argument("--ransac-budget", type=int, default=100000, help="hypotheses per job of the fixed-budget RANSAC figure (0 = skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                              # does not return
     preset = CONFIGS[args.config]
     for k in ("model", "memory", "points"):
         if getattr(args, k) is None:
@@ -286,6 +320,12 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.layout == "sharded" or (args.layout == "auto" and world_size > 1 and not args.shard_clouds):
+        args.shard_memory = True
+    if args.comm is None:      # (the one-GPU rehearsal with every rank on device 0 cannot use RCCL: it refuses two ranks per device)
+        args.comm = "rccl" if args.shard_memory and os.environ.get("IBL_BENCH_SHARE_GPU", "") != "1" else "torch"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     # rehearsal of the multi-rank flow on a one-GPU box (not a measurement): IBL_BENCH_SHARE_GPU=1 puts every rank on device 0 and
     # uses gloo for the barrier / max-over-ranks (RCCL refuses two ranks on one device)
     share_gpu = os.environ.get("IBL_BENCH_SHARE_GPU", "") == "1"
@@ -295,8 +335,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if share_gpu else "nccl")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -344,6 +382,7 @@ def main():
     value = total_frames / dt
     roof_live = prof.roofline(None)                       # before the untimed stage-timing step below adds launches
     roof_iso = None
+    stage_roofs = []
     if not args.sequential:                               # per-stage device times of one step run back to back, outside the timed region
         # (averaged over up to four different batches: a batch with a job that never reaches RANSAC's confidence exit walks all 4 M
         # hypotheses, or whose targets lie far apart, can double its "register" time -- one such batch is not the typical step)
@@ -358,6 +397,25 @@ def main():
         if os.environ.get("IBL_TIMING") or os.environ.get("IBL_BENCH_DEBUG"):
             print("[bench] stage timings of the extra steps:", {k: v for k, v in timings.items() if isinstance(v, float)}, file=sys.stderr)
         roof_iso = prof.roofline(None)                    # the same GEMM launches with nothing else on the device
+        stage_roofs = prof.stage_rooflines() if args.register else []     # one entry per registration stage, same steps
+        for e in stage_roofs:
+            e["ms_per_step"] = e.pop("ms") / n_extra
+            e["work_per_step"] = e.pop("work") / n_extra
+        # SURVEY 8d's fixed-budget RANSAC figure: H hypotheses per job with the confidence exit off (never the product setting)
+        if args.register and args.ransac_budget > 0 and not args.shard_clouds:
+            prof.reset(enable=True)
+            b = batches[args.warmup + args.steps - 1]
+            eng.localise_batch(b["det"], b["qs"], crops=b["crops"], seed=args.seed, ransac_max_iter=args.ransac_budget,
+                               ransac_fixed_budget=True, **kw)
+            torch.cuda.synchronize()
+            ms, hyp, n = prof.read(prof.ST_RANSAC)
+            if n and ms > 0:
+                stage_roofs.append({"stage": "RANSAC fixed budget (a12)", "bound": "valu", "achieved": hyp / (ms * 1e-3) / 1e6, "peak": None,
+                                    "unit": "Mhyp/s", "frac": None, "ms_per_step": ms, "calls": n, "work_per_step": hyp,
+                                    "work_unit": f"H = {args.ransac_budget} hypotheses per job, confidence exit off, {int(hyp // args.ransac_budget)} jobs; "
+                                    "each = Philox draw + edge-length test, survivors (~1 %) get the 3-point Kabsch + distance check + scoring on "
+                                    "all correspondences (the checkers prune before scoring, as in Open3D)"})
+            prof.reset(enable=False)
 
     # accuracy signals against the generator's ground truth (outside the timed region)
     n_frames = n_assn_ok = n_ok = n_ok_given = n_any = 0
@@ -387,8 +445,19 @@ def main():
         if roof is not None and roof_iso is not None:
             roof["note"] = ("pipelined steps: these launches share the device with the registration kernels of the previous step, so the "
                             "duration of a launch is not the kernel's own speed; roofline_isolated times the same launches alone; "
-                            "traffic: PMC counters cannot be read in-process -- the FETCH_SIZE / WRITE_SIZE passes of this command are "
-                            "under profiles/ (tools/profile_pmc.sh)")
+                            "traffic: PMC counters cannot be read in-process -- traffic_from_profile is the FETCH_SIZE / WRITE_SIZE result "
+                            "of the committed rocprofv3 --pmc passes (tools/profile_pmc.sh)")
+        pmc_file = os.path.join(ROOT, "profiles", "r03", "gemm_pmc.json")
+        if roof is not None and os.path.exists(pmc_file):
+            try:
+                pm = json.load(open(pmc_file))
+                tp = {"bytes_per_launch": pm.get("traffic_bytes_per_launch"), "algorithmic_bytes_per_launch": pm.get("algorithmic_bytes_per_launch"),
+                      "file": "profiles/r03/gemm_pmc.json"}
+                roof["traffic_from_profile"] = tp
+                if roof_iso is not None:
+                    roof_iso["traffic_from_profile"] = tp
+            except (OSError, ValueError):
+                pass
         cpu = None
         cpu_frames = args.cpu_frames if args.cpu_frames is not None else (6 if args.register else 24)
         if cpu_frames > 0 and world_size == 1:            # the CPU leg is timed on rank 0 of the single-GPU run only
@@ -413,16 +482,23 @@ def main():
             "vs_baseline": None,
             "dtype": "f16 (ViT MFMA operands, f32 accumulate) / f32+f64 (match, registration)",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {args.model} {crop_desc} (Q={args.q}), {args.memory}-instance memory (E={args.views}), {stages}",
+            "config": {"workload": f"{args.config}: {args.model} {crop_desc} (Q={args.q}), {args.memory}-instance memory (E={args.views}), {stages}"
+                       + ("; synthetic objects of extent U[0.15, 0.6] m on a %.2f m grid (SURVEY 8d's U[0.2, 1.5] m re-scoped: its 5 000 points "
+                          "are too sparse to survive the radius-outlier removal)" % args.spacing if args.register else ""),
                        "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
-                       "points_per_object": args.points,
-                       "parallelism": f"frames-dp{world_size}" + ("+memory-shard%d(%s)" % (world_size, args.comm) if args.shard_memory else "")
-                       + ("+cloud-shard%d" % world_size if args.shard_clouds else "")},
+                       "points_per_object": args.points, "object_spacing_m": args.spacing,
+                       "parallelism": f"frames-dp{world_size}" + ("+memory-shard%d(%s)" % (world_size, args.comm) if args.shard_memory else "+memory-replicated")
+                       + ("+cloud-shard%d" % world_size if args.shard_clouds else ""),
+                       "rccl_ranks": (eng.exchange.comm.world if eng.exchange is not None and eng.exchange.comm is not None
+                                      else (world_size if world_size > 1 and not share_gpu else None))},
             # `roofline`: HIP events around every GEMM launch of the timed region.  With pipelined steps the embed stream shares the
             # device with the registration kernels of the previous step, so a launch's duration there is not the kernel's own
             # speed; `roofline_isolated` is the same measurement over the launches of one extra step run alone afterwards.
             "roofline": roof,
             "roofline_isolated": roof_iso,
+            # SURVEY 8d "report each stage separately": the registration stages of the same isolated steps (HIP events on the launch
+            # stream around each stage's launches x algorithmic work), plus the fixed-budget RANSAC figure
+            "roofline_stages": stage_roofs,
             "cpu_baseline": cpu,
             "pipelined_steps": not args.sequential,
             "stage_ms_per_step": {k: v / (args.steps if args.sequential else 1) for k, v in timings.items() if isinstance(v, float)},

@@ -56,6 +56,7 @@ int ibl_prof_read(int id, double* ms, double* units, int64_t* launches);
 #define IBL_VIT_QUICK_GELU 8      /* x*sigmoid(1.702x) (OpenAI CLIP); laion2b ViT-B-32 uses GELU   */
 #define IBL_VIT_PROJ 16           /* CLS -> out_dim projection (CLIP visual.proj)                  */
 #define IBL_VIT_OUT_ALL_TOKENS 32 /* return every token (DATOR/TransReID local_feature=True)       */
+#define IBL_VIT_SPLIT_SCALE 64.0f /* S of the two-term operands below                              */
 
 typedef struct {
     int32_t dim, depth, heads, mlp_dim;
@@ -77,6 +78,19 @@ typedef struct {                   /* all [dev]; weights fp16 [N][K] row-major (
     const void* w_fc1;  const float* b_fc1;     /* [mlp_dim][dim]                                     */
     const void* w_fc2;  const float* b_fc2;     /* [dim][mlp_dim]                                     */
     const float* ls2;
+    /* Optional two-term fp16 operands (round 3; all NULL / 0 = plain fp16 operands, what rounds 1-2 ran).  With random-init
+     * weights the first blocks carry most of the encoder's fp16 rounding error (the residual stream is still small there), so
+     * the host may hand those blocks their weights as W = W_hi + W_lo (both fp16, W_lo stored times IBL_VIT_SPLIT_SCALE so it
+     * stays a normal number) and ask for the LayerNorm output as a_hi + a_lo as well.  K-extended operand rows:
+     *   terms 2: A' = [a_hi | a_hi / S],             W' = [W_hi | W_lo * S]              (weights exact to ~2^-22)
+     *   terms 3: A' = [a_hi | a_lo * S | a_hi / S],  W' = [W_hi | W_hi / S | W_lo * S]   (+ the activation's second term)
+     * one accumulation, same kernel, K' = terms * dim.  The two residual GEMMs (linear epilogue) take the second weight term
+     * as a second launch that accumulates scale_lo[n] * (a W_lo'^T) into the residual (scale_lo = LayerScale / S, or 1 / S). */
+    const void* w_qkv_x;                         /* fp16 [3*dim][qkv_terms*dim] or NULL                */
+    const void* w_o_lo;  const float* ls1_lo;   /* fp16 [dim][dim] = W_lo * S; fp32 [dim] = ls1 / S   */
+    const void* w_fc1_x;                         /* fp16 [mlp_dim][fc1_terms*dim] or NULL              */
+    const void* w_fc2_lo; const float* ls2_lo;  /* fp16 [dim][mlp_dim]; fp32 [dim]                    */
+    int32_t qkv_terms, fc1_terms;                /* 1 (or 0), 2 or 3                                   */
 } ibl_vit_layer;
 
 typedef struct {
@@ -88,6 +102,7 @@ typedef struct {
     const float* ln_pre_g; const float* ln_pre_b;
     const float* ln_f_g;   const float* ln_f_b;
     const void* w_proj;            /* fp16 [out_dim][dim] or NULL                                    */
+    const void* w_patch_lo;        /* optional fp16 [dim][patch_k_pad] = (W - fp16(W)) * S: second term of the patch weights  */
     ibl_vit_layer layers[IBL_VIT_MAX_LAYERS];
 } ibl_vit_weights;
 
@@ -262,6 +277,10 @@ int ibl_comm_init(ibl_comm** out, int rank, int world, const void* unique_id, in
 int ibl_comm_destroy(ibl_comm* comm);
 /* recv [dev] world x bytes_per_rank: the contribution of rank r at offset r * bytes_per_rank */
 int ibl_allgather_topk(ibl_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+/* Equal-block all-to-all (ncclSend / ncclRecv pairs in one group): block r of `send` ([world][bytes_per_pair]) goes to rank r, block r
+ * of `recv` comes from rank r.  The exchange of the per-shard candidate lists since round 3: the owner of a query row receives the
+ * `world` lists of that row and nothing else (the all-gather above delivered every rank's lists to every rank). */
+int ibl_alltoall(ibl_comm* comm, const void* send, void* recv, int64_t bytes_per_pair, void* stream);
 /* in place, element-wise minimum over the ranks of n floats (ibl_evaluate_points distances) */
 int ibl_allreduce_min(ibl_comm* comm, float* buf, int64_t n, void* stream);
 /* in place, element-wise maximum of n int32 (the "some rank needs the full rows" flag of a step) */
@@ -341,6 +360,8 @@ int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* s
  * ransac_stats_out [n_jobs][3] = (hypotheses walked, validated, best inlier count) or NULL. */
 #define IBL_REG_HAVE_COLORS 1
 #define IBL_REG_CENTER 2
+#define IBL_REG_FIXED_BUDGET 4   /* RANSAC walks exactly ransac_max_iter hypotheses per job (confidence exit off): the fixed-budget
+                                    hypotheses/s figure of the benchmark, never the product setting */
 int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
                        int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
                        int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs, double voxel_size,

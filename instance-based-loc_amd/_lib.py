@@ -82,6 +82,7 @@ _SIGS = {
     "ibl_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
     "ibl_comm_destroy": (C.c_int, [vp]),
     "ibl_allgather_topk": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "ibl_alltoall": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "ibl_allreduce_min": (C.c_int, [vp, vp, C.c_int64, vp]),
     "ibl_allreduce_max_i32": (C.c_int, [vp, vp, C.c_int64, vp]),
     "ibl_topk_select": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),

@@ -58,6 +58,22 @@ extern "C" int ibl_allgather_topk(ibl_comm* c, const void* send, void* recv, int
     return IBL_OK;
 }
 
+// equal-block all-to-all (ncclSend / ncclRecv pairs in one group): block r of `send` goes to rank r, block r of `recv` comes from it.
+// The per-shard candidate lists of the sharded match: each rank ends up with the W lists of ITS OWN query rows only.
+extern "C" int ibl_alltoall(ibl_comm* c, const void* send, void* recv, int64_t bytes_per_pair, void* stream) {
+    if (!c || !send || !recv || bytes_per_pair < 0) return ibl_set_error(IBL_ERR_ARG, "ibl_alltoall: bad argument");
+    if (bytes_per_pair == 0) return IBL_OK;
+    IBL_NCCL_CHECK(ncclGroupStart());
+    for (int r = 0; r < c->world; ++r) {
+        IBL_NCCL_CHECK(ncclSend(reinterpret_cast<const char*>(send) + (size_t)r * bytes_per_pair, (size_t)bytes_per_pair, ncclInt8, r, c->comm,
+                                (hipStream_t)stream));
+        IBL_NCCL_CHECK(ncclRecv(reinterpret_cast<char*>(recv) + (size_t)r * bytes_per_pair, (size_t)bytes_per_pair, ncclInt8, r, c->comm,
+                                (hipStream_t)stream));
+    }
+    IBL_NCCL_CHECK(ncclGroupEnd());
+    return IBL_OK;
+}
+
 extern "C" int ibl_allreduce_min(ibl_comm* c, float* buf, int64_t n, void* stream) {
     if (!c || !buf || n < 0) return ibl_set_error(IBL_ERR_ARG, "ibl_allreduce_min: bad argument");
     if (n == 0) return IBL_OK;

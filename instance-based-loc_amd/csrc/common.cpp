@@ -61,6 +61,13 @@ void ibl_prof_end(void* token, void* stream) {
     if (i < g_pending.size()) (void)hipEventRecord(g_pending[i].b, (hipStream_t)stream);
 }
 
+void ibl_prof_set_units(void* token, double units) {
+    if (!token) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t i = reinterpret_cast<size_t>(token) - 1;
+    if (i < g_pending.size()) g_pending[i].units = units;
+}
+
 static void prof_drain() {
     for (auto& p : g_pending) {
         float ms = 0.f;

@@ -34,9 +34,17 @@ int ibl_set_error(int code, const char* fmt, ...);
 #define IBL_PROF_ICP 7         // ibl_icp_step_kernel: 56 B per source point
 #define IBL_PROF_RANSAC 8      // ibl_ransac_flag_kernel: hypotheses
 #define IBL_PROF_ROWSIM 9      // ibl_rowsim_kernel: 2*rows*queries*dim FLOPs
-#define IBL_PROF_MAX 16
+// whole stages of the registration side (bench.py's per-stage roofline): one event pair around the stage's launches
+#define IBL_PROF_ST_FEATURES 10   // ibl_instance_features_batch: 444 B per point (normals 24 + SPFH 156 + FPFH 264)
+#define IBL_PROF_ST_FEATMATCH 11  // feature search of a registration call: 4*33*Ns*Nt FLOPs per job (both directions)
+#define IBL_PROF_ST_RANSAC 12     // RANSAC of a registration call: hypotheses walked (all jobs)
+#define IBL_PROF_ST_ICP 13        // ICP of a registration call: 56 B per source point and iteration run
+#define IBL_PROF_ST_EVAL 14       // ibl_evaluate_*: 24 B per detected point and candidate
+#define IBL_PROF_ST_OUTLIER 15    // ibl_radius_outlier_batch: 12 B in + 1 B out per point
+#define IBL_PROF_MAX 24
 int ibl_prof_enabled();
 void ibl_prof_begin(int id, double units, void* stream, void** token);
 void ibl_prof_end(void* token, void* stream);
+void ibl_prof_set_units(void* token, double units);      // units known only after the stage ran (iterations, hypotheses)
 
 static inline int64_t ibl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -117,10 +117,14 @@ extern "C" int ibl_radius_outlier_batch(ibl_reg_ctx* ctx, const float* pts4, con
     ArenaMark mark(ctx);
     hipStream_t s = (hipStream_t)stream;
     BatchGrid g;
+    void* tok;
+    ibl_prof_begin(IBL_PROF_ST_OUTLIER, 13.0 * (double)seg_off_host[n_seg], s, &tok);
     st = ibl_build_batch_grid(ctx, reinterpret_cast<const float4*>(pts4), seg_off_dev, seg_off_host, n_seg, (float)radius,
                               (int64_t)64 << 20, &g, s);
     if (st) return st;
-    return ibl_launch_radius_count(g, reinterpret_cast<const float4*>(pts4), seg_off_dev, seg_off_host[n_seg], radius, nb_points, keep, s);
+    st = ibl_launch_radius_count(g, reinterpret_cast<const float4*>(pts4), seg_off_dev, seg_off_host[n_seg], radius, nb_points, keep, s);
+    ibl_prof_end(tok, s);
+    return st;
 }
 
 extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
@@ -273,6 +277,8 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
         st = ibl_bbox_to_host(ctx, P, seg_off_dev, n_seg, bbox_host, s);        // the one synchronisation of this call before its end
         if (st) return st;
     }
+    void* tok;
+    ibl_prof_begin(IBL_PROF_ST_FEATURES, 444.0 * (double)(n_seg > 0 ? seg_off_host[n_seg] : 0), s, &tok);
     // chunks of whole clouds bound the scratch (800 B / point of neighbour lists): a 10k-instance memory is 50M points
     const int64_t chunk_pts = 1 << 20;
     std::vector<int> rebased;
@@ -304,6 +310,7 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
             ibl_stage_reset(ctx);
         }
     }
+    ibl_prof_end(tok, s);
     IBL_HIP_CHECK(hipStreamSynchronize(s));
     ibl_stage_reset(ctx);
     return IBL_OK;

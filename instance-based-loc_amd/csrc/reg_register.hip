@@ -715,8 +715,10 @@ __global__ __launch_bounds__(64) void ibl_ransac_fold_kernel(RansacState* __rest
             if (fit > S.best_fit || (fit == S.best_fit && rmse < S.best_rmse)) {
                 S.best_fit = fit; S.best_rmse = rmse; S.best_inl = cinl; S.last_update = ci;
                 if (lane < 12) S.best_T[lane] = e_T[(int64_t)(c0 + t) * 12 + lane];
-                const double ek = log(1.0 - confidence) / log(1.0 - pow(fit, 3.0));
-                if (ek < (double)S.est_k) S.est_k = (long long)ceil(ek);
+                if (confidence > 0.0) {          // (<= 0: fixed budget, IBL_REG_FIXED_BUDGET)
+                    const double ek = log(1.0 - confidence) / log(1.0 - pow(fit, 3.0));
+                    if (ek < (double)S.est_k) S.est_k = (long long)ceil(ek);
+                }
             }
         }
         // survivors of this chunk that the reference loop walks: it stands at max(last update + 1, est_k)
@@ -994,6 +996,7 @@ __global__ __launch_bounds__(64) void ibl_icp_update_kernel(IcpState* __restrict
 // the fused driver
 // ------------------------------------------------------------------------------------------------
 static thread_local bool tl_force_valu = false;     // set while a call is redone after the matrix-core search overflowed its list
+static thread_local bool tl_ransac_full_list = false;   // set while a call is redone after a RANSAC round overflowed the survivor list
 static thread_local const uint32_t* tl_job_ids = nullptr;   // ibl_register_batch_ids: the caller's job ids for the duration of its call
 
 __global__ void ibl_status_clear_kernel(int* __restrict__ status, int mask) { atomicAnd(status, ~mask); }
@@ -1043,8 +1046,10 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     const int J = n_jobs;
     const bool colored = (flags & IBL_REG_HAVE_COLORS) != 0;
     const bool center = (flags & IBL_REG_CENTER) != 0;
+    const int flags_in = flags;        // (`flags` names a RANSAC scratch array further down)
     hipStream_t s = (hipStream_t)stream;
     ArenaMark mark(ctx);
+    void *tok_match = nullptr, *tok_ransac = nullptr, *tok_icp = nullptr;       // stage brackets of the in-process timer (bench.py)
     hipLaunchKernelGGL(ibl_status_clear_kernel, dim3(1), dim3(1), 0, s, ctx->d_status, IBL_ST_FEAT_OVERFLOW | IBL_ST_RANSAC_OVERFLOW);
     IBL_LAUNCH_CHECK();
     const bool timing = getenv("IBL_TIMING") != nullptr;
@@ -1437,6 +1442,11 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                     }
                 }
                 phase("recomputed groups + assemble");
+                {
+                    double fl = 0;
+                    for (int j = 0; j < J; ++j) fl += 4.0 * 33.0 * (double)(job_off[j + 1] - job_off[j]) * (double)(job_off[J + j + 1] - job_off[J + j]);
+                    ibl_prof_begin(IBL_PROF_ST_FEATMATCH, fl, s, &tok_match);
+                }
                 // matching reads the features in place (caches / recomputed groups), once per distinct pair
                 st = ibl_stage_upload(ctx, d_sides, sides.data(), sizeof(SidePairs) * (int64_t)sides.size(), s);
                 if (st) return st;
@@ -1512,6 +1522,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 }
                 // (the group scratch released here is reused by later kernels of the same stream only: no synchronisation)
             }
+            ibl_prof_end(tok_match, s);
             phase("feature search");
             hipLaunchKernelGGL(ibl_mutual_kernel, dim3(J), dim3(256), 0, s, nn, d_job_off, J, 1, 9, corr, n_corr);
             IBL_LAUNCH_CHECK();
@@ -1519,6 +1530,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         // ---- RANSAC ----------------------------------------------------------------------------------
         {
             ArenaMark m3(ctx);
+            ibl_prof_begin(IBL_PROF_ST_RANSAC, 0.0, s, &tok_ransac);
             const double max_dist = voxel_size * global_dist_factor;
             const int max_round = RANSAC_MAX_ROUND;
             // a round's tables hold (active jobs) x (round size) hypotheses; when only a few jobs are left (wrong assignments
@@ -1530,7 +1542,9 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             IBL_ARENA(flags, unsigned char, cap_slots);
             IBL_ARENA(blk_cnt, int, cap_blk + 1);
             IBL_ARENA(blk_off, int, cap_blk + 1);
-            const int list_cap = (int)std::min<int64_t>(cap_slots / 16 + 65536, (int64_t)1 << 27);
+            // survivors of the edge-length test of one round: ~1 % of the hypotheses on real clouds; a batch whose round exceeds the list is
+            // redone once with a list that holds every hypothesis (tl_ransac_full_list, below)
+            const int list_cap = (int)std::min<int64_t>(tl_ransac_full_list ? cap_slots + 65536 : cap_slots / 16 + 65536, (int64_t)1 << 27);
             IBL_ARENA(list, int, list_cap);
             int *e_inl, *e_job; double *e_err2, *e_T;
             IBL_ARENA(e_inl, int, list_cap);
@@ -1585,7 +1599,8 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 hipLaunchKernelGGL(ibl_ransac_score_kernel, dim3(4096), dim3(256), 0, s, cp, d_job_off, n_corr, max_dist, total_ptr, list_cap, e_job,
                                    e_T, e_inl, e_err2);
                 IBL_LAUNCH_CHECK();
-                hipLaunchKernelGGL(ibl_ransac_fold_kernel, dim3(n_act), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter, 0.99, round_size,
+                hipLaunchKernelGGL(ibl_ransac_fold_kernel, dim3(n_act), dim3(64), 0, s, rs, J, n_corr, (long long)ransac_max_iter,
+                                   (flags_in & IBL_REG_FIXED_BUDGET) ? -1.0 : 0.99, round_size,
                                    blk_off, list, e_inl, e_err2, e_T, active);
                 IBL_LAUNCH_CHECK();
                 return IBL_OK;
@@ -1619,8 +1634,10 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             }
         }
     }
+    ibl_prof_end(tok_ransac, s);
     phase("ransac");
     // ---- ICP ------------------------------------------------------------------------------------------
+    ibl_prof_begin(IBL_PROF_ST_ICP, 0.0, s, &tok_icp);
     {
         double* partial; int* icp_nn; float* icp_d2;
         IBL_ARENA(partial, double, (int64_t)J * ICP_BPJ * ICP_NACC);
@@ -1642,6 +1659,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             IBL_LAUNCH_CHECK();
         }
     }
+    ibl_prof_end(tok_icp, s);
     phase("icp");
     // ---- results ----------------------------------------------------------------------------------------
     std::vector<IcpState> h_is(J);
@@ -1657,6 +1675,27 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
     IBL_HIP_CHECK(hipMemcpyAsync(&h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     IBL_HIP_CHECK(hipStreamSynchronize(s));
     ibl_stage_reset(ctx);
+    if (tok_icp || tok_ransac) {                 // stage units known now: iterations run per job, hypotheses walked
+        double icp_b = 0, hyp = 0;
+        for (int j = 0; j < J; ++j) {
+            icp_b += 56.0 * (double)(job_off[j + 1] - job_off[j]) * (double)std::max(1, h_is[j].iter);
+            if (!h_rs.empty()) hyp += (double)h_rs[j].walked;
+        }
+        ibl_prof_set_units(tok_icp, icp_b);
+        ibl_prof_set_units(tok_ransac, hyp);
+    }
+    if ((h_status & IBL_ST_RANSAC_OVERFLOW) && !tl_ransac_full_list) {
+        // more edge-test survivors in one round than the list holds (near-identical clouds, a loose edge criterion): the results of this
+        // pass are unusable -- once more with a list that holds every hypothesis of a round (same hypotheses, same fold order: same result
+        // as a pass whose list never overflowed)
+        tl_ransac_full_list = true;
+        const int st2 = ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
+                                                  job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed,
+                                                  job_id_base, ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out,
+                                                  means_out, T_ransac_out, ransac_stats_out, reuse_stats_out, stream);
+        tl_ransac_full_list = false;
+        return st2;
+    }
     if (h_status & IBL_ST_RANSAC_OVERFLOW)
         return ibl_set_error(IBL_ERR_OVERFLOW, "ransac: the surviving hypotheses of one round exceed the list capacity");
     if ((h_status & IBL_ST_FEAT_OVERFLOW) && !tl_force_valu) {
@@ -1898,8 +1937,11 @@ static int evaluate_impl(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float*
     IBL_ARENA(d_jobs, EvalJob, J);
     IBL_ARENA(partial, double, (int64_t)J * ICP_BPJ * 2);
     IBL_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(EvalJob) * J, hipMemcpyHostToDevice, s));
+    void* tok;
+    ibl_prof_begin(IBL_PROF_ST_EVAL, 24.0 * (double)(jobs[J - 1].out + (jobs[J - 1].end - jobs[J - 1].begin)), s, &tok);
     hipLaunchKernelGGL(ibl_evaluate_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, *grid, reinterpret_cast<const float4*>(det_pts4), d_jobs,
                        (float)threshold, (float)(threshold * threshold), partial, d2_out);
+    ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     std::vector<double> h((size_t)J * ICP_BPJ * 2);
     IBL_HIP_CHECK(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));

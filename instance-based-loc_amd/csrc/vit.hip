@@ -46,6 +46,9 @@ struct GemmEpi {
     int64_t ldo;            // output row stride (elements)
     int tokens_per_crop;    // T (EPI_PATCH)
     int patches_per_crop;   // P (EPI_PATCH)
+    int accumulate;         // EPI_PATCH: x += alpha * acc instead of x = acc + bias + pos (second weight term of a two-term operand)
+    float alpha;
+    int algo_k;             // K the in-process timer counts as algorithmic (0: K itself; -1: none -- extra terms of a two-term operand are overhead, not model FLOPs)
 };
 
 constexpr int GBK = 64;                 // K granule every caller guarantees (K % 64 == 0)
@@ -508,11 +511,21 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
             const int b = row / epi.patches_per_crop, p = row - b * epi.patches_per_crop;
             const int64_t orow = (int64_t)b * epi.tokens_per_crop + 1 + p;
             float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(epi.out) + orow * epi.ldo + n0);
-            const float4* ps = reinterpret_cast<const float4*>(epi.pos + (int64_t)p * N + n0);
+            if (epi.accumulate) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 pp = ps[q];
-                o[q] = make_float4(v[4 * q] + pp.x, v[4 * q + 1] + pp.y, v[4 * q + 2] + pp.z, v[4 * q + 3] + pp.w);
+                for (int q = 0; q < 4; ++q) {
+                    float4 xx = o[q];
+                    xx.x = fmaf(v[4 * q], epi.alpha, xx.x); xx.y = fmaf(v[4 * q + 1], epi.alpha, xx.y);
+                    xx.z = fmaf(v[4 * q + 2], epi.alpha, xx.z); xx.w = fmaf(v[4 * q + 3], epi.alpha, xx.w);
+                    o[q] = xx;
+                }
+            } else {
+                const float4* ps = reinterpret_cast<const float4*>(epi.pos + (int64_t)p * N + n0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 pp = ps[q];
+                    o[q] = make_float4(v[4 * q] + pp.x, v[4 * q + 1] + pp.y, v[4 * q + 2] + pp.z, v[4 * q + 3] + pp.w);
+                }
             }
         } else {
             float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + n0);
@@ -570,7 +583,7 @@ static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw,
         if (grid > cus * OCC) grid = cus * OCC;
     }
     void* tok;
-    ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, s, &tok);
+    ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)(epi.algo_k < 0 ? 0 : (epi.algo_k ? epi.algo_k : K)), s, &tok);
     hipLaunchKernelGGL((ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS, PIPE>), dim3(grid), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
@@ -624,7 +637,8 @@ static int launch_gemm(const u16* A, int64_t lda, const u16* W, int64_t ldw, int
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, fp32 in -> fp16 out (or fp32 out for the final CLS rows)
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_F32>
+// TERMS (fp16 output only): 1 = the row; 2 = [a_hi | a_hi / S]; 3 = [a_hi | a_lo * S | a_hi / S] (two-term operand rows, ibloc.h)
+template <bool OUT_F32, int TERMS = 1>
 __global__ __launch_bounds__(256) void ibl_layernorm_kernel(const float* x, int64_t in_row_stride,
                                                             int64_t n_rows, int dim, const float* __restrict__ g,
                                                             const float* __restrict__ b, float eps, void* out,
@@ -677,14 +691,37 @@ __global__ __launch_bounds__(256) void ibl_layernorm_kernel(const float* x, int6
             } else {
                 ushort4 o;
                 o.x = f2h(y0); o.y = f2h(y1); o.z = f2h(y2); o.w = f2h(y3);
-                *reinterpret_cast<ushort4*>(reinterpret_cast<u16*>(out) + row * out_row_stride + c0) = o;
+                u16* orow = reinterpret_cast<u16*>(out) + row * out_row_stride;
+                *reinterpret_cast<ushort4*>(orow + c0) = o;
+                if (TERMS > 1) {
+                    const float h0 = (float)__builtin_bit_cast(_Float16, o.x), h1 = (float)__builtin_bit_cast(_Float16, o.y);
+                    const float h2 = (float)__builtin_bit_cast(_Float16, o.z), h3 = (float)__builtin_bit_cast(_Float16, o.w);
+                    constexpr float S = IBL_VIT_SPLIT_SCALE, IS = 1.0f / IBL_VIT_SPLIT_SCALE;
+                    ushort4 d;
+                    d.x = f2h(h0 * IS); d.y = f2h(h1 * IS); d.z = f2h(h2 * IS); d.w = f2h(h3 * IS);
+                    *reinterpret_cast<ushort4*>(orow + (TERMS - 1) * dim + c0) = d;
+                    if (TERMS == 3) {
+                        ushort4 l;
+                        l.x = f2h((y0 - h0) * S); l.y = f2h((y1 - h1) * S); l.z = f2h((y2 - h2) * S); l.w = f2h((y3 - h3) * S);
+                        *reinterpret_cast<ushort4*>(orow + dim + c0) = l;
+                    }
+                }
             }
         }
     int t = 0;
     for (int i = rem0 + lane; i < dim; i += 64, ++t) {
         const float y = (tail[t] - mean) * rstd * g[i] + b[i];
         if (OUT_F32) reinterpret_cast<float*>(out)[row * out_row_stride + i] = y;
-        else reinterpret_cast<u16*>(out)[row * out_row_stride + i] = f2h(y);
+        else {
+            u16* orow = reinterpret_cast<u16*>(out) + row * out_row_stride;
+            const u16 hb = f2h(y);
+            orow[i] = hb;
+            if (TERMS > 1) {
+                const float hf = (float)__builtin_bit_cast(_Float16, hb);
+                orow[(TERMS - 1) * dim + i] = f2h(hf * (1.0f / IBL_VIT_SPLIT_SCALE));
+                if (TERMS == 3) orow[dim + i] = f2h((y - hf) * IBL_VIT_SPLIT_SCALE);
+            }
+        }
     }
 }
 
@@ -873,7 +910,7 @@ extern "C" int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* d, int batch) {
     const int64_t R = rows_pad((int64_t)batch * d->n_tokens);
     int64_t bytes = 0;
     bytes += R * d->dim * 4;          // x
-    bytes += R * d->dim * 2;          // xn
+    bytes += R * d->dim * 2 * 3;      // xn (up to three terms per row, two-term operands of the early blocks)
     bytes += R * 3 * d->dim * 2;      // qkv
     bytes += R * d->dim * 2;          // attn out
     bytes += R * d->mlp_dim * 2;      // mlp hidden
@@ -927,7 +964,7 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
     };
     unsigned char* p = reinterpret_cast<unsigned char*>(workspace);
     float* x = reinterpret_cast<float*>(carve(p, R * D * 4));
-    u16* xn = reinterpret_cast<u16*>(carve(p, R * D * 2));
+    u16* xn = reinterpret_cast<u16*>(carve(p, R * D * 2 * 3));
     u16* qkv = reinterpret_cast<u16*>(carve(p, R * 3 * D * 2));
     u16* att = reinterpret_cast<u16*>(carve(p, R * D * 2));
     u16* hid = reinterpret_cast<u16*>(carve(p, R * d->mlp_dim * 2));
@@ -942,6 +979,14 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
                                         reinterpret_cast<const u16*>(w->w_patch), d->patch_k_pad, batch * P, D,
                                         d->patch_k_pad, e, s);
         if (st) return st;
+        if (w->w_patch_lo) {             // second term of the patch weights: x += (patches W_lo'^T) / S
+            GemmEpi e2 = e;
+            e2.bias = nullptr; e2.accumulate = 1; e2.alpha = 1.0f / IBL_VIT_SPLIT_SCALE; e2.algo_k = -1;
+            st = launch_gemm<EPI_PATCH_F32>(reinterpret_cast<const u16*>(patches), d->patch_k_pad,
+                                            reinterpret_cast<const u16*>(w->w_patch_lo), d->patch_k_pad, batch * P, D,
+                                            d->patch_k_pad, e2, s);
+            if (st) return st;
+        }
         const int64_t n = (int64_t)batch * D;
         hipLaunchKernelGGL(ibl_set_cls_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w->cls_pos, batch,
                            T, D);
@@ -962,13 +1007,23 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
         // bit-identical).  The kernels take row strides, the CLS rows are addressed in place (stride T * D).
         const bool cls_only = (l == d->n_blocks_run - 1) && !(d->flags & IBL_VIT_OUT_ALL_TOKENS);
         const int64_t TD = (int64_t)T * D;
-        hipLaunchKernelGGL(ibl_layernorm_kernel<false>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, L->ln1_g,
-                           L->ln1_b, d->ln_eps, (void*)xn, (int64_t)D);
+        // two-term operands (ibloc.h): only in blocks that run on every row (the CLS-only last block stays plain)
+        const int qt = (!cls_only && L->w_qkv_x && L->qkv_terms > 1) ? L->qkv_terms : 1;
+        const int ft = (!cls_only && L->w_fc1_x && L->fc1_terms > 1) ? L->fc1_terms : 1;
+        if (qt > 3 || ft > 3) return ibl_set_error(IBL_ERR_ARG, "ibl_vit_forward: layer %d: at most three operand terms", l);
+#define IBL_LN_TERMS(terms, g_, b_)                                                                                                 \
+        do {                                                                                                                            \
+            if ((terms) == 1) hipLaunchKernelGGL((ibl_layernorm_kernel<false, 1>), ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, g_, b_, d->ln_eps, (void*)xn, (int64_t)D);            \
+            else if ((terms) == 2) hipLaunchKernelGGL((ibl_layernorm_kernel<false, 2>), ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, g_, b_, d->ln_eps, (void*)xn, (int64_t)2 * D);   \
+            else hipLaunchKernelGGL((ibl_layernorm_kernel<false, 3>), ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, g_, b_, d->ln_eps, (void*)xn, (int64_t)3 * D);                      \
+        } while (0)
+        IBL_LN_TERMS(qt, L->ln1_g, L->ln1_b);
         IBL_LAUNCH_CHECK();
         if (!cls_only) {
             GemmEpi e{};
-            e.bias = L->b_qkv; e.out = qkv; e.ldo = 3 * D;
-            st = launch_gemm<EPI_BIAS_H16>(xn, D, reinterpret_cast<const u16*>(L->w_qkv), D, (int)Rn, 3 * D, D, e, s);
+            e.bias = L->b_qkv; e.out = qkv; e.ldo = 3 * D; e.algo_k = D;
+            st = launch_gemm<EPI_BIAS_H16>(xn, (int64_t)qt * D, reinterpret_cast<const u16*>(qt > 1 ? L->w_qkv_x : L->w_qkv), (int64_t)qt * D, (int)Rn,
+                                           3 * D, qt * D, e, s);
             if (st) return st;
         } else {
             GemmEpi e{};                                  // keys and values of every token: weight rows D .. 3D
@@ -988,10 +1043,14 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
             st = launch_gemm<EPI_RESID_F32>(att, cls_only ? TD : D, reinterpret_cast<const u16*>(L->w_o), D, cls_only ? batch : (int)Rn, D, D,
                                             e, s);
             if (st) return st;
+            if (!cls_only && L->w_o_lo && L->ls1_lo) {       // second weight term: x += (ls1 / S) * (att W_lo'^T)
+                e.bias = nullptr; e.scale = L->ls1_lo; e.algo_k = -1;
+                st = launch_gemm<EPI_RESID_F32>(att, D, reinterpret_cast<const u16*>(L->w_o_lo), D, (int)Rn, D, D, e, s);
+                if (st) return st;
+            }
         }
         if (!cls_only) {
-            hipLaunchKernelGGL(ibl_layernorm_kernel<false>, ln_grid, dim3(256), 0, s, x, (int64_t)D, Rn, D, L->ln2_g,
-                               L->ln2_b, d->ln_eps, (void*)xn, (int64_t)D);
+            IBL_LN_TERMS(ft, L->ln2_g, L->ln2_b);
         } else {
             hipLaunchKernelGGL(ibl_layernorm_kernel<false>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, x, TD, (int64_t)batch, D,
                                L->ln2_g, L->ln2_b, d->ln_eps, (void*)fin_bf, (int64_t)D);
@@ -1001,10 +1060,11 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
         const int mlp_rows = cls_only ? batch : (int)Rn;
         {
             GemmEpi e{};
-            e.bias = L->b_fc1; e.out = hid; e.ldo = d->mlp_dim;
+            e.bias = L->b_fc1; e.out = hid; e.ldo = d->mlp_dim; e.algo_k = D;
             if (d->flags & IBL_VIT_QUICK_GELU)
                 return ibl_set_error(IBL_ERR_UNSUPPORTED, "ibl_vit_forward: QuickGELU not built");
-            st = launch_gemm<EPI_BIAS_GELU_H16>(mlp_in, D, reinterpret_cast<const u16*>(L->w_fc1), D, mlp_rows, d->mlp_dim, D, e, s);
+            st = launch_gemm<EPI_BIAS_GELU_H16>(mlp_in, (int64_t)ft * D, reinterpret_cast<const u16*>(ft > 1 ? L->w_fc1_x : L->w_fc1), (int64_t)ft * D,
+                                                mlp_rows, d->mlp_dim, ft * D, e, s);
             if (st) return st;
         }
         {
@@ -1012,8 +1072,14 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
             e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = cls_only ? TD : D;
             st = launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
             if (st) return st;
+            if (!cls_only && L->w_fc2_lo && L->ls2_lo) {
+                e.bias = nullptr; e.scale = L->ls2_lo; e.algo_k = -1;
+                st = launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2_lo), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
+                if (st) return st;
+            }
         }
     }
+#undef IBL_LN_TERMS
     if (d->flags & IBL_VIT_OUT_ALL_TOKENS) {
         // DATOR streams: all tokens, optionally through the final LayerNorm
         if (d->flags & IBL_VIT_FINAL_LN) {

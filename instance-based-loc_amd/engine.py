@@ -170,22 +170,35 @@ class LocaliseEngine:
         mem = self.memory
         q_per_frame = np.asarray(q_per_frame, dtype=np.int32)
         F = len(q_per_frame)
-        if (q_per_frame > 7).any():
-            raise ValueError("more than 7 detections in a frame: select the 7 largest first (object_memory.py:900-908)")
+        ex = self.exchange
+        # input checks first; with a sharded memory the ranks then AGREE on the outcome before the step's collectives (one all-reduce
+        # of flags): a rank that raised alone would leave the others waiting in the all-gather forever
         q_emb = np.minimum(q_per_frame, mem.M).astype(np.int32)      # Q > M truncates the detections that are matched (:918-920)
-        if (q_emb < np.minimum(q_per_frame, 3)).any():
-            raise AssertionError("fewer memory objects than the sub-volume dimension (reference asserts at similarity_volume.py:112)")
+        err = None
+        if (q_per_frame > 7).any():
+            err = ValueError("more than 7 detections in a frame: select the 7 largest first (object_memory.py:900-908)")
+        elif (q_emb < np.minimum(q_per_frame, 3)).any():
+            err = AssertionError("fewer memory objects than the sub-volume dimension (reference asserts at similarity_volume.py:112)")
+        elif det_emb is None and self.encoder is None:
+            err = ValueError("no encoder: pass det_emb")
+        elif ex is not None and int(q_per_frame.sum()) > ex.cap:
+            err = ValueError(f"{int(q_per_frame.sum())} query rows in a step, rows_cap is {ex.cap}")
+        if ex is not None:
+            any_err, any_done, _ = ex.agree(err is not None, False, mem.device)
+            if err is None and any_done:
+                err = RuntimeError("sharded memory: another rank has run out of batches (every rank must localise the same number of batches)")
+            if err is None and any_err:
+                err = RuntimeError("sharded memory: another rank rejected its inputs for this step; no rank runs it")
+        if err is not None:
+            raise err
         row0 = np.concatenate([[0], np.cumsum(q_per_frame)]).astype(np.int32)
         if det_emb is None:
-            if self.encoder is None:
-                raise ValueError("no encoder: pass det_emb")
             det_emb = self.encoder.embed(crops, lane=lane)
         else:
             det_emb = torch.as_tensor(det_emb, dtype=torch.float32, device=mem.device).contiguous()
         tick("embed")
         detn = match.normalize_rows(det_emb)                                        # :924
         R = detn.shape[0]
-        ex = self.exchange
         if ex is None:
             val, idx, cnt, aug = match.match_topk(detn, mem.mem_emb, mem.emb_offsets, self.k_hi, self.k_lo, 0)   # :933-936 + sim_volume :13-18
             tick("match")
@@ -317,12 +330,24 @@ class LocaliseEngine:
             ready.record(main)
             return self._pool_a.submit(stage_a, b, ready)
 
+        def stage_done():
+            # sharded memory: tell the other ranks this one has no batch left -- if any of them still has one, every rank raises
+            # instead of that rank waiting for this one in its all-gather (issued by the stage-A thread, like every collective)
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(side):
+                _, _, any_active = self.exchange.agree(False, True, dev)
+            if any_active:
+                raise RuntimeError("sharded memory: the ranks were given different numbers of batches")
+
+        fut_done = None
         it = iter(batches)
         cur = next(it, None)
-        if cur is None:
-            return
         if self._pool_a is None:
             self._pool_a = ThreadPoolExecutor(max_workers=1)
+        if cur is None:
+            if self.exchange is not None:
+                self._pool_a.submit(stage_done).result()
+            return
         fut = submit(cur)
         try:
             while cur is not None:
@@ -331,12 +356,16 @@ class LocaliseEngine:
                 nxt = next(it, None)
                 if nxt is not None:
                     fut = submit(nxt)
+                elif self.exchange is not None:
+                    fut_done = self._pool_a.submit(stage_done)
                 args = dict(kw)
                 for k in ("seed", "job_id_base"):
                     if k in cur:
                         args[k] = cur[k]
                 yield self.localise_batch(cur["det"], cur["q_per_frame"], assns=assns, **args)
                 cur = nxt
+            if fut_done is not None:
+                fut_done.result()
         finally:
             # an abandoned generator or a raising batch must not leave stage A running on the side stream with the lane-0 encoder
             # workspace: a later localise_batch on the caller's stream would race with it
@@ -380,8 +409,9 @@ class LocaliseEngine:
         ids = (np.uint32(job_id_base) + np.arange(J, dtype=np.uint32)).astype(np.uint32)
         src = np.asarray(job_src, dtype=np.int64).reshape(-1, 3)
         tgt = np.asarray(job_tgt, dtype=np.int64).reshape(-1, 3)
+        params = (int(seed), float(voxel), float(gdf), float(ldf), int(ransac_max_iter))     # a shipped job runs with these: equal on all ranks
         reg, _ = routed_register(self.route, mem.M, clean.pts4, clean.seg_off_host, src, tgt, ids, store, mem.inst_sizes_all, compute,
-                                 self.route_stats)
+                                 self.route_stats, params=params)
         return reg
 
     def _evaluate_routed(self, ctx, clean, jb, je, G, thr):
@@ -398,7 +428,7 @@ class LocaliseEngine:
     def localise_batch(self, det: CloudBatch, q_per_frame, crops=None, det_emb=None, fpfh_voxel_size=0.05,
                        fpfh_global_dist_factor=2, fpfh_local_dist_factor=0.4, outlier_radius=0.05, outlier_nb_points=8,
                        seed=0, job_id_base=0, ransac_max_iter=4000000, num_per_length=4, eval_threshold=None, timings=None,
-                       assns=None, _slot=None, register=True):
+                       assns=None, _slot=None, register=True, ransac_fixed_budget=False):
         """det: detected clouds of all frames (segments in frame order, <= 7 per frame); crops: uint8 tensor
         (sum Q, H, W, 3) or list of arrays (DATOR: the (rgb, depth) pair), or det_emb: (sum Q, D) precomputed embeddings (or
         assns: the assignment lists stage A of `localise_stream` produced).  register=False stops after the assignment search
@@ -472,7 +502,7 @@ class LocaliseEngine:
         else:
             reg = register_batch(ctx, clean, mem.clouds, job_src, job_tgt, fpfh_voxel_size, fpfh_global_dist_factor,
                                  fpfh_local_dist_factor, seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter,
-                                 have_colors=True, center=True, det_features=det_feat, mem_features=mem_feat)
+                                 have_colors=True, center=True, det_features=det_feat, mem_features=mem_feat, fixed_budget=ransac_fixed_budget)
             if timings is not None:
                 timings["reuse"] = reg["reuse"].tolist()
         tick("register")

@@ -6,8 +6,10 @@ xGMI on ROCm; "gloo" in the CPU tests).
     1. all-gathers the L2-normalised query embeddings of all ranks (R x D fp32 per rank; 688 KB for 224 rows of 768),
     2. matches ALL ranks' rows against ITS instance range and keeps, per row, the k_hi largest / k_lo smallest fp16 similarities
        with their GLOBAL instance indices (`ibl_match_topk`, csrc/topk.hip),
-    3. all-gathers those candidate lists ((6 S + 8) bytes per row and shard, S = k_hi + k_lo: 1.3 KB -- the north star's "RCCL
-       all-gather of per-shard top-k matches over xGMI before registration"),
+    3. exchanges those candidate lists ((6 S + 8) bytes per row and shard, S = k_hi + k_lo: 1.3 KB -- the north star's "RCCL
+       all-gather of per-shard top-k matches over xGMI before registration"; since round 3 as an all-to-all: the owner of a row
+       receives the W per-shard lists of that row, W * cap * 1.3 KB = 2.4 MB per rank and step at W = 8, cap = 224, where the
+       all-gather delivered every rank's lists to everyone, W times as much),
    and the owner of a frame merges the per-shard lists and runs the assignment search on them (`ibl_assign_candidates`), which proves
    per frame that the result equals the search on the full rows.  A frame it cannot prove (ties at the candidate threshold) is redone
    on full rows: the ranks agree with one all-reduce(MAX) of a flag and all-gather their similarity blocks for that step only.
@@ -109,6 +111,14 @@ class RcclComm:
         self._lib.check(self._lib.lib.ibl_allgather_topk(self._h, mine.data_ptr(), out.data_ptr(), mine.numel() * mine.element_size(),
                                                          torch.cuda.current_stream().cuda_stream), "ibl_allgather_topk")
 
+    def all_to_all(self, out: torch.Tensor, mine: torch.Tensor):
+        """equal blocks: block r of `mine` goes to rank r, block r of `out` comes from rank r"""
+        assert out.is_contiguous() and mine.is_contiguous() and out.numel() == mine.numel() and out.dtype == mine.dtype
+        nbytes = mine.numel() * mine.element_size()
+        assert nbytes % self.world == 0
+        self._lib.check(self._lib.lib.ibl_alltoall(self._h, mine.data_ptr(), out.data_ptr(), nbytes // self.world,
+                                                   torch.cuda.current_stream().cuda_stream), "ibl_alltoall")
+
     def all_reduce_min(self, buf: torch.Tensor):
         assert buf.dtype == torch.float32 and buf.is_contiguous()
         self._lib.check(self._lib.lib.ibl_allreduce_min(self._h, buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream),
@@ -152,11 +162,29 @@ class ShardExchange:
     def gather_candidates(self, val: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor):
         """This rank's lists for all W * cap rows -> the lists of every shard for THIS rank's rows: (W, cap, S) / (W, cap, S) / (W, cap, 2)."""
         S = val.shape[1]
-        mine = pack_candidates(val, idx, cnt)                             # (W * cap, P)
-        out = torch.empty((self.world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
-        self._all_gather(out, mine)                                        # (concatenated form: the one gloo implements too)
-        own = out.view(self.world, mine.shape[0], mine.shape[1])[:, self.rank * self.cap:(self.rank + 1) * self.cap]     # (W, cap, P)
-        return unpack_candidates(own, S)
+        mine = pack_candidates(val, idx, cnt)                             # (W * cap, P): block r = my shard's lists for rank r's rows
+        # all-to-all: rank r receives only the W x cap lists of ITS rows (W * cap * P ints per rank and step; an all-gather of `mine`
+        # delivered W times that and every rank kept 1 / W of it)
+        own = torch.empty_like(mine)
+        if self.comm is not None:
+            self.comm.all_to_all(own, mine)
+        elif self.world == 1:
+            own.copy_(mine)
+        else:
+            dist.all_to_all_single(own, mine, group=self.group)
+        return unpack_candidates(own.view(self.world, self.cap, mine.shape[1]), S)
+
+    def agree(self, error: bool, done: bool, device):
+        """One all-reduce(MAX) of (error, done, active) flags at the start of a step: a rank that found an error in its inputs, or ran
+        out of batches, must not leave the others waiting in the step's collectives -- every rank learns it and raises.  Returns
+        (any rank has an error, any rank is done, any rank is active)."""
+        t = torch.tensor([1 if error else 0, 1 if done else 0, 0 if done else 1], dtype=torch.int32, device=device)
+        if self.comm is not None:
+            self.comm.all_reduce_max_i32(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        e, d, a = (bool(v) for v in t.tolist())
+        return e, d, a
 
     def any_flag(self, flag: bool, device) -> bool:
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)

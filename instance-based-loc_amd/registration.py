@@ -180,12 +180,13 @@ def instance_features_batch(ctx: RegContext, batch: CloudBatch, voxel_size: floa
 
 REG_HAVE_COLORS = 1
 REG_CENTER = 2
+REG_FIXED_BUDGET = 4        # benchmark only: RANSAC walks exactly ransac_max_iter hypotheses per job (no confidence exit)
 
 
 def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_seg, job_tgt_seg, voxel_size,
                    global_dist_factor=1.5, local_dist_factor=0.4, seed=0, job_id_base=0, ransac_max_iter=4000000,
                    have_colors=True, center=True, det_features: InstanceFeatures = None, mem_features: InstanceFeatures = None,
-                   job_ids=None):
+                   job_ids=None, fixed_budget=False):
     """Batched register_point_clouds (utils/fpfh_register.py:100-143).  job_*_seg: (J, <=3) int arrays of
     pool segment ids (-1 padded).  det_features / mem_features: instance features of the two pools
     (instance_features_batch); the results do not depend on them, only the work does.  Returns dict of host arrays:
@@ -209,7 +210,7 @@ def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_se
     means = np.zeros((J, 2, 3), dtype=np.float64)
     Tr = np.zeros((J, 16), dtype=np.float64)
     stats = np.zeros((J, 3), dtype=np.int64)
-    flags = (REG_HAVE_COLORS if have_colors else 0) | (REG_CENTER if center else 0)
+    flags = (REG_HAVE_COLORS if have_colors else 0) | (REG_CENTER if center else 0) | (REG_FIXED_BUDGET if fixed_budget else 0)
     reuse = np.zeros(6, dtype=np.int64)
     df = det_features.as_struct() if det_features is not None else None
     mf = mem_features.as_struct() if mem_features is not None else None

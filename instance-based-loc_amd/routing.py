@@ -14,7 +14,7 @@ Every rank localises its own frames ("home" of their jobs) and owns the clouds +
      the batch they were computed in, so the result is bit-identical to the unsharded run);
   5. results (a few hundred bytes per job) return to the home ranks;
   6. whole-memory evaluation: the cleaned detected points and the global transforms are all-gathered, every rank measures every job
-     against the points it owns, all-reduce(MIN) of the per-point squared distances (parallel.evaluate_sharded).
+     against the points it owns, reduce-scatter(MIN) of the per-point squared distances (a rank only needs its own jobs' minima).
 
 The transport is torch.distributed ("nccl" = RCCL over xGMI; "gloo" with host staging in the tests).  Everything here that is not a
 collective is a pure function of the gathered tables, so the ranks cannot disagree on message sizes or orders.
@@ -122,6 +122,26 @@ class Transport:
         dist.all_reduce(c, op=dist.ReduceOp.MIN, group=self.group)
         return c.to(t.device)
 
+    def reduce_scatter_min(self, t: torch.Tensor, sizes) -> torch.Tensor:
+        """t = the sections of all ranks back to back (sizes[r] elements for rank r), the same layout on every rank -> the element-wise
+        minimum over the ranks of THIS rank's section.  RCCL: one reduce-scatter on sections padded to the longest (each rank receives
+        1 / W of what the all-reduce moved to everyone); gloo has no reduce-scatter: all-reduce, then slice."""
+        start = int(sum(sizes[:self.rank]))
+        n = int(sizes[self.rank])
+        if self.world == 1:
+            return t[start:start + n]
+        if dist.get_backend(self.group) != "nccl":
+            return self.all_reduce_min(t)[start:start + n]
+        nmax = max(int(x) for x in sizes)
+        pad = torch.full((self.world, max(nmax, 1)), float("inf"), dtype=t.dtype, device=self.comm_device)
+        o = 0
+        for r, k in enumerate(sizes):
+            pad[r, :int(k)] = t[o:o + int(k)]
+            o += int(k)
+        out = torch.empty(max(nmax, 1), dtype=t.dtype, device=self.comm_device)
+        dist.reduce_scatter_tensor(out, pad.view(-1), op=dist.ReduceOp.MIN, group=self.group)
+        return out[:n].to(t.device)
+
 
 def _bytes(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous().view(torch.uint8).reshape(-1)
@@ -162,17 +182,23 @@ class InstanceStore:
 
 
 def routed_register(tr: Transport, M: int, det_pts: torch.Tensor, det_off: np.ndarray, job_src, job_tgt, job_ids, store: InstanceStore,
-                    inst_sizes_all: np.ndarray, compute, stats: dict = None):
+                    inst_sizes_all: np.ndarray, compute, stats: dict = None, params=None):
     """Collective.  det_pts (N, 4) float32 + det_off (S + 1): this rank's cleaned detected segments; job_src (J, 3) segment ids, job_tgt
     (J, 3) global instance ids, job_ids (J,) uint32; store: the instances this rank owns; inst_sizes_all (M,): points of every instance.
     compute(det_pts, det_off, n_home_segs, arrays, per_instance, mem_off, js, jt, ids) -> dict of (J_exec, ...) numpy arrays runs the job
-    list of this rank (pool-relative indices).  Returns the dict for THIS rank's J jobs, in their order."""
+    list of this rank (pool-relative indices).  Returns the dict for THIS rank's J jobs, in their order.
+    params: whatever `compute` applies to EVERY job it runs (seed, radii, iteration caps): a shipped job runs with the executor's
+    values, so they travel with the job tables and must be equal on all ranks -- otherwise every rank raises (a job's result must not
+    depend on where it ran)."""
     me, W = tr.rank, tr.world
     det_off = np.asarray(det_off, dtype=np.int64)
     job_src = np.asarray(job_src, dtype=np.int64).reshape(-1, 3)
     job_tgt = np.asarray(job_tgt, dtype=np.int64).reshape(-1, 3)
     job_ids = np.asarray(job_ids, dtype=np.uint32).reshape(-1)
-    metas = tr.all_gather_object({"src": job_src, "tgt": job_tgt, "ids": job_ids, "seg": np.diff(det_off)})
+    metas = tr.all_gather_object({"src": job_src, "tgt": job_tgt, "ids": job_ids, "seg": np.diff(det_off), "params": params})
+    if any(m["params"] != metas[0]["params"] for m in metas):
+        raise ValueError("routed registration: the ranks passed different registration parameters "
+                         f"({[m['params'] for m in metas]}); a shipped job would run with its executor's values")
     plan = plan_routes([m["src"] for m in metas], [m["tgt"] for m in metas], M, W)
     dev = det_pts.device
     row_b, inst_b = store.row_bytes(), store.inst_bytes()
@@ -308,6 +334,5 @@ def routed_evaluate(tr: Transport, clean_pts: torch.Tensor, job_begin, job_end, 
             d2_parts.append(evaluate_points_local(pts_all[r], m["jb"], m["je"], m["G"]))
     if not d2_parts:
         return np.zeros(0), np.zeros(0)
-    d2 = tr.all_reduce_min(torch.cat(d2_parts))
-    start = int(sum(sizes[:tr.rank]))
-    return fitness_rmse_from_d2(d2[start:start + sizes[tr.rank]], (je - jb).tolist())
+    d2 = tr.reduce_scatter_min(torch.cat(d2_parts), sizes)          # each rank only needs the minima of its own jobs
+    return fitness_rmse_from_d2(d2, (je - jb).tolist())

@@ -31,12 +31,62 @@ class VitDesc(C.Structure):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ls1", "ln2_g", "ln2_b",
-                                          "w_fc1", "b_fc1", "w_fc2", "b_fc2", "ls2")]
+                                          "w_fc1", "b_fc1", "w_fc2", "b_fc2", "ls2",
+                                          "w_qkv_x", "w_o_lo", "ls1_lo", "w_fc1_x", "w_fc2_lo", "ls2_lo")] + \
+               [("qkv_terms", C.c_int32), ("fc1_terms", C.c_int32)]
 
 
 class VitWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w_patch", "b_patch", "cls_pos", "pos_patch", "ln_pre_g", "ln_pre_b",
-                                          "ln_f_g", "ln_f_b", "w_proj")] + [("layers", VitLayer * MAX_LAYERS)]
+                                          "ln_f_g", "ln_f_b", "w_proj", "w_patch_lo")] + [("layers", VitLayer * MAX_LAYERS)]
+
+
+SPLIT_SCALE = 64.0          # IBL_VIT_SPLIT_SCALE (include/ibloc.h)
+
+# Which operands of which blocks get a second fp16 term ("p<terms>;<layer>:<qkv><o><fc1><fc2>;..."; qkv / fc1: 1, 2 (weights) or 3
+# (weights + LayerNorm output), o / fc2 / p(atch embedding): 1 or 2 (weights)).  Measured on the 12-layer ViT-B/14 with the seeded
+# random-init weights (DESIGN (c), tools/sim_vit_rounding.py): the residual stream is small in the first blocks, so the patch
+# embedding (18 % of the error variance at 1.3 % of the FLOPs), block 0 (46 %) and block 1 (14 %) carry most of the fp16 rounding
+# error of the embedding; the default gives them exact weights where that is cheap.  "plain" = one term everywhere (rounds 1-2).
+DEFAULT_PRECISION = "p2;0:3222;1:2211"
+
+
+def parse_precision(spec):
+    """-> (patch_terms, {layer: (qkv, o, fc1, fc2)})"""
+    if spec in (None, "", "default"):
+        spec = DEFAULT_PRECISION
+    if spec == "plain":
+        return 1, {}
+    patch, layers = 1, {}
+    for part in spec.split(";"):
+        part = part.strip()
+        if not part:
+            continue
+        if part[0] == "p":
+            patch = int(part[1:])
+        else:
+            l, t = part.split(":")
+            t = tuple(int(c) for c in t)
+            if len(t) != 4 or not all(1 <= v <= 3 for v in t) or t[1] > 2 or t[3] > 2:
+                raise ValueError(f"bad precision entry {part!r}")
+            layers[int(l)] = t
+    if patch not in (1, 2):
+        raise ValueError("patch terms: 1 or 2")
+    return patch, layers
+
+
+def split_terms(w, terms):
+    """fp32 weight (N, K) -> K-extended fp16 operand rows [W_hi | W_lo * S] (terms 2) or [W_hi | W_hi / S | W_lo * S] (terms 3)"""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    hi = w.astype(np.float16).astype(np.float32)
+    lo = (w - hi) * SPLIT_SCALE
+    parts = [hi, lo] if terms == 2 else [hi, hi / SPLIT_SCALE, lo]
+    return np.concatenate(parts, axis=1)
+
+
+def weight_lo(w):
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    return (w - w.astype(np.float16).astype(np.float32)) * SPLIT_SCALE
 
 
 @dataclass
@@ -167,9 +217,13 @@ def interpolate_pos_embed(pos: np.ndarray, cfg: VitConfig) -> np.ndarray:
 class VitEncoder:
     """Device-resident weights + batched forward through the C-ABI."""
 
-    def __init__(self, cfg: VitConfig, weights: dict, device="cuda"):
+    def __init__(self, cfg: VitConfig, weights: dict, device="cuda", precision=None):
+        """precision: operand-term plan (see DEFAULT_PRECISION; None = $IBL_VIT_PREC or the default, "plain" = fp16 operands only)"""
         if cfg.depth > MAX_LAYERS:
             raise ValueError("too many layers")
+        import os
+        self.precision = precision if precision is not None else os.environ.get("IBL_VIT_PREC", DEFAULT_PRECISION)
+        patch_terms, layer_terms = parse_precision(self.precision)
         self.cfg = cfg
         self.device = torch.device(device)
         self._keep = []                     # device tensors referenced by the structs
@@ -189,6 +243,8 @@ class VitEncoder:
         wp[:, :cfg.patch_k] = weights["patch.w"].reshape(cfg.dim, -1)
         W = VitWeights()
         W.w_patch = dev_f16(wp)
+        if patch_terms == 2:
+            W.w_patch_lo = dev_f16(weight_lo(wp))
         W.b_patch = dev_f32(weights["patch.b"]) if "patch.b" in weights else None
         W.cls_pos = dev_f32(weights["cls"].reshape(-1) + pos[0])
         W.pos_patch = dev_f32(pos[1:])
@@ -210,6 +266,22 @@ class VitEncoder:
             L.w_fc2, L.b_fc2 = dev_f16(weights[p + "fc2.w"]), dev_f32(weights[p + "fc2.b"])
             if cfg.layerscale:
                 L.ls1, L.ls2 = dev_f32(weights[p + "ls1"]), dev_f32(weights[p + "ls2"])
+            nrun_ = cfg.depth if cfg.n_blocks_run < 0 else cfg.n_blocks_run
+            if l in layer_terms and not (l == nrun_ - 1 and not cfg.out_all_tokens):     # the CLS-only last block stays plain
+                tq, to, t1, t2 = layer_terms[l]
+                ones = np.ones(cfg.dim, dtype=np.float32)
+                if tq > 1:
+                    L.w_qkv_x = dev_f16(split_terms(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0), tq))
+                    L.qkv_terms = tq
+                if to > 1:
+                    L.w_o_lo = dev_f16(weight_lo(weights[p + "o.w"]))
+                    L.ls1_lo = dev_f32((weights[p + "ls1"] if cfg.layerscale else ones) / SPLIT_SCALE)
+                if t1 > 1:
+                    L.w_fc1_x = dev_f16(split_terms(weights[p + "fc1.w"], t1))
+                    L.fc1_terms = t1
+                if t2 > 1:
+                    L.w_fc2_lo = dev_f16(weight_lo(weights[p + "fc2.w"]))
+                    L.ls2_lo = dev_f32((weights[p + "ls2"] if cfg.layerscale else ones) / SPLIT_SCALE)
         self.W = W
         flags = 0
         flags |= FLAG_LAYERSCALE if cfg.layerscale else 0

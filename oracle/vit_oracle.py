@@ -71,7 +71,10 @@ def vit_forward(weights: dict, cfg, pixel_values: np.ndarray, all_tokens=False, 
     tests embed tens of thousands of crops; gfx950 has no reduced-precision fp32 matmul mode, the arithmetic stays fp32)."""
     F = torch.nn.functional
     w = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v, dtype=np.float32))).to(device) for k, v in weights.items()}
-    x = torch.from_numpy(np.asarray(pixel_values, dtype=np.float32)).to(device)
+    if isinstance(pixel_values, torch.Tensor):       # already a float32 tensor (the parity tests normalise u8 crops on the device)
+        x = pixel_values.to(device=device, dtype=torch.float32)
+    else:
+        x = torch.from_numpy(np.asarray(pixel_values, dtype=np.float32)).to(device)
     B = x.shape[0]
     x = F.conv2d(x, w["patch.w"], w.get("patch.b"), stride=cfg.patch)           # (B, D, gh, gw)
     x = x.flatten(2).transpose(1, 2)

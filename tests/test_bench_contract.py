@@ -25,3 +25,20 @@ def test_committed_bench_line_has_the_contract_fields():
     # round 2: the default workload is BASELINE's metric row (M = 10 000) and says how honest the synthetic detections are
     assert d["config"]["memory_instances"] == 10000 and d["config"]["workload"].startswith("T:")
     assert d["det_points_after_outlier_mean"] >= 4000 and d["assignment_correct_rate"] >= 0.95 and d["registered_given_correct_assignment"] >= 0.95
+
+
+def test_bench_gpus_2_starts_two_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must start two ranks as child processes and exit non-zero when they fail --
+    on this GPU-less box every rank stops with the "needs an MI355X" message (--gpus was parsed and never read)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():          # (on a GPU box the run would succeed or fail for other reasons: nothing to check here)
+        return
+    assert out.returncode != 0
+    assert "starting 2 ranks" in out.stderr and "--nproc-per-node=2" in out.stderr
+    assert out.stderr.count("needs an MI355X") == 2, out.stderr[-2000:]
+    assert not out.stdout.strip().startswith("{")           # no JSON line from a failed run

@@ -1,6 +1,7 @@
 """-m gpu: what the fp16 operands of the HIP encoder cost DOWNSTREAM.  The same crops go through the HIP encoder and through the
 fp32 oracle (torch fp32, evaluated on the GPU so that a 10 000-instance memory -- 40 000 crops -- is embedded in a minute); both
-embedding sets are matched and assigned by the same exact code; reported: the embedding error, the share of fp16 `aug` entries that
+embedding sets are matched and assigned by the same exact code (round 3: crops are generated and normalised on the device, so the
+10 000-instance case -- 2 x 40 000 crops -- runs in the default suite); reported: the embedding error, the share of fp16 `aug` entries that
 differ, and the share of frames whose assignment LIST differs -- the one quantity of the path the north star calls bit-exact "given
 identical embeddings".  The numbers are recorded in DESIGN.md (c); the assertions are loose upper bounds of what was measured.
 
@@ -16,9 +17,7 @@ from oracle import vit_oracle as vo
 pytestmark = pytest.mark.gpu
 
 
-def _world(M, E, F, seed):
-    import bench
-    crops = bench.Crops("dinov2_vitb14", seed)
+def _frames(M, F, seed):
     rng = np.random.default_rng(seed)
     side = int(np.ceil(np.sqrt(M)))
     frames = []
@@ -28,46 +27,81 @@ def _world(M, E, F, seed):
         ids = [k for dy in (-1, 0, 1) for dx in (-1, 0, 1) for k in [(gy + dy) * side + gx + dx]
                if 0 <= gx + dx < side and 0 <= gy + dy < side and k < M][:7]
         frames.append(ids)
-    return crops, rng, frames
+    return frames
 
 
-def _embed_both(enc, w, cfg, crops_u8):
-    """crops (N, 224, 224, 3) u8 host array -> (HIP embeddings, fp32 oracle embeddings), both (N, D) numpy"""
-    from ibloc_amd import preprocess as pp
+class GpuCrops:
+    """The bench's synthetic crops (bench.Crops: a distinct low-frequency pattern per instance + pixel noise per view), generated on
+    the device so that 2 x 40 000 crops cost seconds instead of minutes of numpy.  Test data only -- the values need not equal
+    bench.Crops', only their statistics."""
+
+    def __init__(self, seed, hw=(224, 224)):
+        self.seed, self.hw = seed, hw
+        h, w = hw
+        self.yy, self.xx = torch.meshgrid(torch.linspace(0, 1, h, device="cuda"), torch.linspace(0, 1, w, device="cuda"), indexing="ij")
+        self.gen = torch.Generator(device="cuda")
+        self.gen.manual_seed(seed)
+
+    def base(self, ids):
+        par = np.stack([np.random.default_rng([self.seed, int(k)]).uniform(size=(3, 4, 4)) for k in ids])      # (n, ch, term, [fx fy ph amp])
+        par = torch.from_numpy(par).to("cuda", torch.float32)
+        fx, fy = 0.5 + 5.5 * par[..., 0], 0.5 + 5.5 * par[..., 1]
+        ph, amp = 2 * np.pi * par[..., 2], 0.3 + 0.7 * par[..., 3]
+        arg = 2 * np.pi * (fx[..., None, None] * self.xx + fy[..., None, None] * self.yy) + ph[..., None, None]
+        img = (amp[..., None, None] * torch.sin(arg)).sum(2)                       # (n, ch, h, w)
+        lo = img.amin(dim=(1, 2, 3), keepdim=True)
+        hi = img.amax(dim=(1, 2, 3), keepdim=True)
+        return ((img - lo) / (hi - lo + 1e-9)).permute(0, 2, 3, 1).contiguous()     # (n, h, w, ch) in [0, 1]
+
+    def variants(self, ids, chunk=256):
+        """(len(ids), h, w, 3) u8 device tensor: one noisy view per entry of ids"""
+        out = []
+        ids = np.asarray(ids)
+        for i in range(0, len(ids), chunk):
+            b = self.base(ids[i:i + chunk])
+            v = b + 0.03 * torch.randn(b.shape, device="cuda", generator=self.gen)
+            out.append((v * 255.0).clamp(0, 255).to(torch.uint8))
+        return torch.cat(out)
+
+
+def _embed_both(enc, wt, cfg, crops_u8, batch=448):
+    """crops (N, 224, 224, 3) u8 device tensor -> (HIP embeddings, fp32 oracle embeddings), both (N, D) numpy.  Both sides start from
+    the SAME resized u8 image (the HIP preprocessing, bit-exact against PIL in test_gpu_vit.py); the oracle normalises it in fp32 and
+    runs the torch fp32 forward on the device."""
+    mean = torch.tensor(enc.recipe.mean, dtype=torch.float32, device="cuda")
+    std = torch.tensor(enc.recipe.std, dtype=torch.float32, device="cuda")
     hip, ora = [], []
-    wt = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)).cuda() for k, v in w.items()}
-    for i in range(0, len(crops_u8), 256):
-        c = crops_u8[i:i + 256]
-        hip.append(enc.embed(torch.from_numpy(c).cuda()).cpu().numpy())
-        ora.append(vo.embed_crops(wt, cfg, pp.RECIPES[cfg.recipe], list(c), device="cuda"))
+    for i in range(0, len(crops_u8), batch):
+        patches, img = enc.preprocess(crops_u8[i:i + batch], want_u8=True)
+        hip.append(enc.forward_patches(patches).cpu().numpy())
+        x = (((img.to(torch.float64) * (1 / 255)).to(torch.float32) - mean) / std).permute(0, 3, 1, 2).contiguous()
+        ora.append(vo.vit_forward(wt, cfg, x, device="cuda"))
     return np.concatenate(hip), np.concatenate(ora)
 
 
+# measured (profiles/r03/parity_flip_rate.txt); the asserted bounds are <= 2x the measured values
 @pytest.mark.parametrize("M,F", [(1000, 64), (10000, 64)], ids=["C2", "T"])
 def test_assignment_flip_rate_fp16_encoder_vs_fp32_oracle(M, F):
-    import os
-    if M > 1000 and not os.environ.get("IBL_FULL_PARITY"):
-        pytest.skip("the 10 000-instance case embeds 2 x 40 000 crops (3 minutes): IBL_FULL_PARITY=1; its output is committed "
-                    "under profiles/r02/parity_flip_rate.txt")
+    from ibloc_amd import match
     from ibloc_amd import vit as V
     from ibloc_amd.engine import LocaliseEngine, MemoryShard
     from ibloc_amd.registration import RegContext
     cfg = V.CONFIGS["dinov2_vitb14"]
     w = V.random_weights(cfg, 20)
+    wt = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)).cuda() for k, v in w.items()}
     enc = V.VitEncoder(cfg, w)
     E = 4
-    crops, rng, frames = _world(M, E, F, 21)
+    crops = GpuCrops(21)
+    frames = _frames(M, F, 21)
     mem_h, mem_o = [], []
     ids_all = np.repeat(np.arange(M), E)
-    for i in range(0, len(ids_all), 1024):
-        u8 = crops.variants(ids_all[i:i + 1024], rng, "cpu").numpy()
-        h, o = _embed_both(enc, w, cfg, u8)
+    for i in range(0, len(ids_all), 1792):
+        h, o = _embed_both(enc, wt, cfg, crops.variants(ids_all[i:i + 1792]))
         mem_h.append(h)
         mem_o.append(o)
-        crops._base.clear()
     mem_h, mem_o = np.concatenate(mem_h).reshape(M, E, -1), np.concatenate(mem_o).reshape(M, E, -1)
     q_ids = [k for f in frames for k in f]
-    det_h, det_o = _embed_both(enc, w, cfg, crops.variants(q_ids, rng, "cpu").numpy())
+    det_h, det_o = _embed_both(enc, wt, cfg, crops.variants(q_ids))
     rel = np.linalg.norm(mem_h - mem_o, axis=-1) / np.linalg.norm(mem_o, axis=-1)
     q = [len(f) for f in frames]
     out = {}
@@ -75,7 +109,6 @@ def test_assignment_flip_rate_fp16_encoder_vs_fp32_oracle(M, F):
     for name, mem, det in (("hip", mem_h, det_h), ("oracle", mem_o, det_o)):
         eng = LocaliseEngine(MemoryShard(ctx, list(mem)))
         res = eng.localise_batch(None, q, det_emb=det, register=False)
-        from ibloc_amd import match
         _, aug = match.closest_similarity(match.normalize_rows(torch.from_numpy(det).cuda()), eng.memory.mem_emb, eng.memory.emb_offsets,
                                           want_sims=False, want_aug=True)
         out[name] = ([r.assignments for r in res], aug.cpu().numpy())
@@ -87,10 +120,16 @@ def test_assignment_flip_rate_fp16_encoder_vs_fp32_oracle(M, F):
     all_correct = []
     for lst in (la, lb):
         all_correct.append(np.mean([all(frames[f][d] == m for a in lst[f] for d, m in a) for f in range(F)]))
-    print(f"[flip M={M}] embedding rel-L2: mean {rel.mean():.2e} max {rel.max():.2e}; fp16 aug entries that differ: {100 * aug_diff:.2f} %; "
-          f"frames with identical assignment lists: {100 * lists_equal:.1f} %; identical best single match: {100 * top1_equal:.1f} %; "
-          f"frames whose every listed pair is a true match: HIP {100 * all_correct[0]:.1f} % / fp32 {100 * all_correct[1]:.1f} %")
-    assert rel.max() < 3e-3
+    line = (f"[flip M={M}] precision plan {enc.precision}: embedding rel-L2 mean {rel.mean():.2e} max {rel.max():.2e} over {rel.size} crops; "
+            f"fp16 aug entries that differ: {100 * aug_diff:.2f} %; "
+            f"frames with identical assignment lists: {100 * lists_equal:.1f} %; identical best single match: {100 * top1_equal:.1f} %; "
+            f"frames whose every listed pair is a true match: HIP {100 * all_correct[0]:.1f} % / fp32 {100 * all_correct[1]:.1f} %")
+    print(line)
+    import os
+    if os.environ.get("IBL_PARITY_LOG"):
+        with open(os.environ["IBL_PARITY_LOG"], "a") as fh:
+            fh.write(line + "\n")
+    assert rel.max() < 1e-3                                    # SURVEY 8d gate: embeddings rel-L2 <= 1e-3 vs the fp32 oracle, every crop
     assert top1_equal == 1.0                                   # the decisive match never moves
     assert abs(all_correct[0] - all_correct[1]) <= 0.05        # ... and the lists are equally right on both sides
 

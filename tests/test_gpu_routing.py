@@ -54,6 +54,14 @@ for a, b in zip(res, ref):
 st = eng.route_stats
 print(f"rank {rank}: {n_jobs} jobs bit-identical; shipped {st['jobs_shipped']}, instances fetched {st['instances_fetched']}, "
       f"bytes sent {st['bytes_sent']}", flush=True)
+# ranks that disagree on a registration parameter (a shipped job would silently run with its executor's seed): EVERY rank must raise,
+# none may be left waiting in a collective (ADVICE r2)
+raised = False
+try:
+    eng.localise_batch(CloudBatch.from_numpy(clouds, ints), qs, **dict(kw, seed=5 + rank))
+except ValueError as e:
+    raised = "different registration parameters" in str(e)
+assert raised, "ranks with different seeds must raise on every rank"
 tot = [None] * world
 dist.all_gather_object(tot, (st["jobs_shipped"], st["instances_fetched"], n_jobs))
 dist.barrier()

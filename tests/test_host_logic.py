@@ -205,6 +205,10 @@ for step, kind in enumerate(["reid", "ties"]):
         assert exact.all(), "re-identification rows must be proved from the candidate lists"
     else:
         assert not exact.all()                           # the fall-back (flag all-reduce + block all-gather) ran on this rank
+# the agreement collective at the start of a step: one rank's input error / end of batches is seen by every rank (ADVICE r2)
+e, d, a = ex.agree(rank == 1, False, "cpu"); assert e and not d and a
+e, d, a = ex.agree(False, rank == 0, "cpu"); assert not e and d and a           # one rank done, one active: both learn of the mismatch
+e, d, a = ex.agree(False, True, "cpu"); assert not e and d and not a            # every rank done: a regular end
 dist.barrier()
 if rank == 0:
     print("TOPK_OK")

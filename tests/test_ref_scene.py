@@ -18,7 +18,9 @@ def test_unprojected_views_land_on_the_saved_memory():
     object of its memory was merged from these views, so a large share of its points is matched to < 1 cm by a single view"""
     objs = rs.memory_objects()
     expect = {1: (0, 0.6), 8: (0, 0.6), 3: (1, 0.35)}             # view -> (object, share of its points the view explains)
-    for k, (depth, rgb, pose) in rs.views().items():
+    vs = rs.views()
+    for k in expect:
+        depth, rgb, pose = vs[k]
         pts, cols = do.coloured_pointcloud_from_depth(depth, rgb, rs.FX, rs.FY)
         T = rs.pose_matrix(pose)
         world = pts.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
@@ -125,3 +127,43 @@ def test_oracle_fpfh_on_a_real_object_matches_an_independent_restatement():
         float(np.median(row_err)), float(np.mean(row_err < 1e-2)), float(np.mean(row_err < 0.5)))
     sums = got.reshape(len(got), 3, 11).sum(-1)
     assert np.all(np.abs(sums - 200) < 0.05)
+
+
+# ---- round 3: all eight views of the reference's room ---------------------------------------------------------------------------
+# tests/golden/ref_scene/oracle_views.json = the oracle's localise() transcript on every view (tools/gen_golden_ref_views.py, 15 minutes of
+# CPU); the -m gpu test compares the HIP path with it view by view.
+ORACLE_FAILS = {2, 7}      # views the ORACLE itself does not localise (see test_every_view_of_the_room_against_its_ground_truth_pose)
+
+
+def test_every_view_of_the_room_against_its_ground_truth_pose():
+    """the reference's success rule (trans < 0.6 m and rot < 0.3 rad, tum_localisation_trial.py:274) against poses.json for all eight
+    views.  Six localise (within 2 cm / 0.02 rad); views 2 and 7 do not, on the oracle and on the device alike: the only well-seen
+    object there is the large armchair from behind (6 900 / 16 400 points against 54 k in memory) and its registration lands half a turn
+    off -- the reference's own log reports 54 of 86 frames localised (new_codebase_results.log:9484-10085)."""
+    o = rs.oracle_views()
+    assert sorted(int(k) for k in o["views"]) == list(range(1, 9))
+    for k, v in o["views"].items():
+        ok = v["gt_err_m"] < 0.6 and v["gt_err_rad"] < 0.3
+        assert ok == (int(k) not in ORACLE_FAILS), (k, v["gt_err_m"], v["gt_err_rad"])
+        if ok:
+            assert v["gt_err_m"] < 0.03 and v["gt_err_rad"] < 0.03
+
+
+def test_stored_oracle_transcript_equals_a_rerun():
+    """the stored transcript is what the oracle computes today: view 4 (one 9.5 k-point detection, 15 s) recomputed"""
+    o = rs.oracle_views()
+    fr = rs.view_frames()[4]
+    v = o["views"]["4"]
+    cleaned, ccols = [], []
+    for pts, inten in zip(fr["clouds"], fr["ints"]):
+        keep = ro.radius_outlier(pts, 0.05, 8)
+        cleaned.append(pts[keep])
+        ccols.append(np.repeat(inten[keep][:, None], 3, axis=1))
+    assert [len(c) for c in cleaned] == v["n_clean"] and fr["seen"] == v["seen"]
+    assns = rs.oracle_assignments(fr["det_emb"])
+    assert assns == v["assignments"]
+    objs = rs.memory_objects()
+    pose, recs, best = ro.localise_from_assignments(cleaned, ccols, [ob[0] for ob in objs], [ob[1] for ob in objs], assns, 0.05, 1.5, 1.5,
+                                                    seed=o["seed"], job_base=v["job_base"], stale_means=False)
+    assert best == v["best"] and np.allclose(pose, v["pose"], atol=1e-9)
+    assert np.allclose([r["full_fitness"] for r in recs], v["full_fitness"], atol=1e-12)

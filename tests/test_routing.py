@@ -129,6 +129,14 @@ fit, rmse = routed_evaluate(tr, torch.from_numpy(det), jb, je, G, eval_local_on(
 from ibloc_amd.parallel import fitness_rmse_from_d2
 fit0, rmse0 = fitness_rmse_from_d2(eval_local_on(full["pts"])(torch.from_numpy(det), jb, je, G), (je - jb).tolist())
 assert np.array_equal(fit, fit0) and np.allclose(rmse, rmse0, rtol=1e-12), (fit, fit0)
+# parameters that every job of an executor shares travel with the job tables: ranks that disagree raise, all of them
+try:
+    routed_register(tr, M, torch.from_numpy(det), det_off, src, tgt, ids, store_for(lo, hi), sizes, compute, {}, params=(7 + rank, 0.05))
+    raise SystemExit("ranks with different parameters did not raise")
+except ValueError as e:
+    assert "different registration parameters" in str(e)
+got2, _ = routed_register(tr, M, torch.from_numpy(det), det_off, src, tgt, ids, store_for(lo, hi), sizes, compute, {}, params=(7, 0.05))
+assert np.array_equal(got2["digest"], ref["digest"])
 dist.barrier()
 if rank == 0:
     print("ROUTING_OK", stats)

@@ -12,6 +12,8 @@ CASES = [
     ("dino_b14_full", "dinov2_vitb14", {"pos_interp": "size"}, 104, 204, 2),
     ("tiny_vit16", "vit_b16", {"dim": 128, "depth": 2, "heads": 2, "mlp_dim": 256}, 105, 205, 3),
     ("tiny_clip", "tiny_clip", {"patch_bias": False}, 106, 206, 3),
+    ("vit_b16_full", "vit_b16", {}, 107, 207, 2),
+    ("clip_b32_full", "clip_b32", {"patch_bias": False}, 108, 208, 2),
 ]
 
 

@@ -4,7 +4,7 @@ stages:
   * out/360_trial_with_floor/objects/{0,1,2}/pointcloud.ply -- a memory the reference saved (ObjectInfo.save, object_info.py:109-118):
     binary little-endian PLY, double x y z + uchar r g b; 11 209 / 53 968 / 9 842 points ("armchair", "armchair", "table",
     memory.txt).  The sibling info.pkl files are NOT read (untrusted pickles holding dummy [1, 2, 3] embeddings).
-  * data/our-synthetic/360_basic_test: views 1, 3 and 8 of its eight 600 x 600 RGB-D views (float32 depth in metres, focal length 300,
+  * data/our-synthetic/360_basic_test: all eight of its 600 x 600 RGB-D views (float32 depth in metres, focal length 300,
     additional_information.txt) and all eight poses of poses.json (position + Euler angles, as the file stores them).
 Run in the build container (the reference tree does not exist on the GPU box):  python tools/gen_fixture_ref_scene.py"""
 import json
@@ -40,7 +40,7 @@ def main():
     views = json.load(open(f"{REF}/data/our-synthetic/360_basic_test/poses.json"))["views"]
     pos = np.array([[v["position"][k] for k in "xyz"] for v in views], dtype=np.float64)
     eul = np.array([[v["rotation"][k] for k in "xyz"] for v in views], dtype=np.float64)
-    keep = [1, 3, 8]
+    keep = list(range(1, 9))        # round 3: all eight views (ground-truth poses of every one are asserted in the tests)
     va = {"position": pos, "euler_xyz_deg": eul, "view_ids": np.array(keep), "focal_length": np.float64(300.0)}
     for k in keep:
         va[f"depth{k}"] = np.load(f"{REF}/data/our-synthetic/360_basic_test/depth/view{k}.npy")

@@ -110,6 +110,9 @@ CASES = [
     ("dino_b14_full", "dinov2_vitb14", {"pos_interp": "size"}, hf_dinov2, 104, 204, 2),
     ("tiny_vit16", "vit_b16", {"dim": 128, "depth": 2, "heads": 2, "mlp_dim": 256}, hf_vit, 105, 205, 3),
     ("tiny_clip", "tiny_clip", {"patch_bias": False}, hf_clip, 106, 206, 3),
+    # full-size a2 / a3 configurations (utils/embeddings.py:74-98 google/vit-base-patch16-224-in21k, :31-50 open_clip ViT-B-32)
+    ("vit_b16_full", "vit_b16", {}, hf_vit, 107, 207, 2),
+    ("clip_b32_full", "clip_b32", {"patch_bias": False}, hf_clip, 108, 208, 2),
 ]
 
 
