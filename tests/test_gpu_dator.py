@@ -34,7 +34,7 @@ def test_head_fp32_vs_oracle(enc):
 
 
 def test_full_forward_vs_oracle_and_reference_golden(enc):
-    """pixels -> embedding through the fp16 streams: rel-L2 <= 3e-3, cosine >= 0.99999 (same bar as the other encoders)"""
+    """pixels -> embedding through the fp16 streams: rel-L2 <= 2.5e-3 (measured 1.25e-3), cosine >= 0.99999"""
     e, _ = enc
     rng = np.random.default_rng(304)
     rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
@@ -44,7 +44,7 @@ def test_full_forward_vs_oracle_and_reference_golden(enc):
     rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     cos = np.min(np.sum(got * ref, -1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(ref, axis=-1)))
     print("dator rel_l2", rel, "cos", cos)
-    assert rel <= 3e-3 and cos >= 0.99999
+    assert rel <= 2.5e-3 and cos >= 0.99999
 
 
 def test_preprocess_and_facade(enc):

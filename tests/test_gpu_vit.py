@@ -1,8 +1,10 @@
 """-m gpu: crop preprocessing (bit-exact u8 vs PIL) and the fp16-MFMA ViT forward vs the fp32 oracle.
 
-Tolerance for the forward: the HIP path multiplies fp16 operands (11-bit significand) with fp32 accumulation and keeps the
-residual stream in fp32; against the fp32 oracle the CLS embedding must agree to rel-L2 <= 3e-3 (2x the measured error of the
-12-layer ViT-B/14, see DESIGN (c); bf16 operands gave 1.1e-2) and cosine >= 0.99999."""
+Tolerance for the forward: the HIP path multiplies fp16 operands (11-bit significand; two fp16 terms for the weights of the first
+blocks, ibloc_amd.vit.DEFAULT_PRECISION) with fp32 accumulation and keeps the residual stream in fp32; against the fp32 oracle the CLS
+embedding must agree to rel-L2 <= 2e-3 on these N(0, 1) pixel tensors (measured: 1.15e-3 ViT-B/14, 1.03e-3 ViT-B/16, 9.8e-4
+CLIP-B/32, 6.6e-4 ViT-S/14; on u8 crops the 12-layer ViT-B/14 measures 7.6e-4 mean / 9.4e-4 max over 40 000 crops,
+tests/test_gpu_flip_rate.py, where the bound is SURVEY 8d's 1e-3) and cosine >= 0.99999."""
 import os
 
 import numpy as np
@@ -61,7 +63,7 @@ def test_forward_vs_oracle(case):
     r, c = rel_l2(got, exp), cosine(got, exp)
     print(f"{key}: rel_l2={r:.3e} cos={c:.6f}")
     assert np.isfinite(got).all()
-    assert r <= 3e-3 and c >= 0.99999
+    assert r <= 2e-3 and c >= 0.99999
 
 
 def test_forward_batch_sizes_and_determinism():
@@ -79,7 +81,7 @@ def test_forward_batch_sizes_and_determinism():
     one = enc.forward_patches(p[:P].contiguous()).cpu().numpy()
     assert np.array_equal(one[0], full[0])          # batch-invariant: each crop is computed independently
     exp = vo.vit_forward(w, cfg, x)
-    assert rel_l2(full, exp) <= 3e-3
+    assert rel_l2(full, exp) <= 2e-3
 
 
 def test_embed_crops_end_to_end():
@@ -92,7 +94,7 @@ def test_embed_crops_end_to_end():
     crops = [rng.integers(0, 256, size=(h, wd, 3), dtype=np.uint8) for h, wd in [(90, 120), (224, 224), (300, 200)]]
     got = enc.embed(crops).cpu().numpy()
     exp = vo.embed_crops(w, cfg, pp.RECIPES["dinov2"], crops)
-    assert rel_l2(got, exp) <= 3e-3 and cosine(got, exp) >= 0.99999
+    assert rel_l2(got, exp) <= 2e-3 and cosine(got, exp) >= 0.99999
 
 
 def test_embed_micro_batches_on_two_streams_equal_one_stream():
