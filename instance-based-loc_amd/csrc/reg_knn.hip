@@ -31,6 +31,18 @@
 #define KNN_GUESS_SHIFT 2      // margin of the threshold-bin guess: + 1 / 4 (12.5 % and 50 % measured 1 % slower)
 #endif
 
+// inclusive prefix sum over the 64 lanes on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 and 31):
+// six VALU instructions, no LDS -- the ds_bpermute form (__shfl_up) cost six LDS round trips, and a query runs three or four scans
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -47,6 +59,20 @@ struct WaveLds {
     float sel_d2[256];
 };
 
+#ifdef KNN_LAB_CLK           // lab builds only: clocks of the phases of a tile's workgroup (thread 0), summed over the tiles
+__device__ unsigned long long knn_lab_clk[16];
+#define KNN_CLK(k)                                                                            \
+    do {                                                                                      \
+        if (threadIdx.x == 0) {                                                               \
+            const long long _t = (long long)__builtin_amdgcn_s_memtime();                     \
+            atomicAdd(&knn_lab_clk[k], (unsigned long long)(_t - _clk_prev));                 \
+            _clk_prev = _t;                                                                   \
+        }                                                                                     \
+    } while (0)
+#else
+#define KNN_CLK(k)
+#endif
+
 // A selected candidate is handed to the consumers as a HANDLE; the accessor turns it into the point and its original index.
 //   GlobalAcc: handle = position in the cell-sorted point array (the per-query walk over the grid, hybrid_select)
 //   TileAcc:   handle = slot of the workgroup's LDS-staged neighbourhood (tile_select)
@@ -59,9 +85,13 @@ struct GlobalAcc {
 struct TileAcc {
     const float4* pts;       // LDS
     const int* ordl;         // LDS
+    int key_base, key_span;  // the original indices of the tile's segment lie in [key_base, key_base + key_span)
     __device__ __forceinline__ float4 pt(int h) const { return pts[h]; }
     __device__ __forceinline__ int ord(int h) const { return ordl[h]; }
 };
+// key range of the handles a consumer sorts by original index: known up front for a tile (its segment), found by a reduction otherwise
+__device__ __forceinline__ bool key_range_hint(const GlobalAcc&, int*, unsigned*) { return false; }
+__device__ __forceinline__ bool key_range_hint(const TileAcc& a, int* kmin, unsigned* span) { *kmin = a.key_base; *span = (unsigned)a.key_span; return true; }
 
 // LDS-staged neighbourhood of one tile (a cube of ts^3 cells): every point of the cube of `rho` cells around the tile, copied once
 // per workgroup and searched by all the tile's queries
@@ -193,12 +223,7 @@ __device__ void hybrid_select(const BatchGrid& g, const SegGrid sg, const float4
     int s = 0;
 #pragma unroll
     for (int t = 0; t < KNN_BINS / 64; ++t) { hb[t] = L->hist[lane * (KNN_BINS / 64) + t]; s += hb[t]; }
-    int incl = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
+    int incl = wave_incl_scan_i(s);
     const int cnt = __shfl(incl, 63, 64);
     const int excl = incl - s;
     const int k = cnt < max_nn ? cnt : max_nn;
@@ -445,17 +470,27 @@ __device__ inline void fast_eigen_normal_d(const double* cov, double* n) {
 template <bool WITH_D2, class Acc>
 __device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const Acc& acc, int k) {
     const int lane = threadIdx.x & 63;
-    if (lane == 0) { L->scratch[62] = 0x7FFFFFFF; L->scratch[63] = -1; }
-    wave_lds_sync();
-    for (int t = lane; t < k; t += 64) {
-        const int key = acc.ord(L->sel_j[t]);
-        L->b_idx[t] = key;
-        atomicMin(&L->scratch[62], key);
-        atomicMax(&L->scratch[63], key);
+    int kmin;
+    unsigned span;
+    if (key_range_hint(acc, &kmin, &span) && span <= 32u * KNN_BINS) {
+        // a tile: every key lies in its segment's index range -- no reduction (64 lanes' atomicMin / atomicMax on one LDS word serialised)
+        for (int t = lane; t < k; t += 64) L->b_idx[t] = acc.ord(L->sel_j[t]);
+        if (span > 0) --span;
+        wave_lds_sync();
+    } else {
+        int mn = 0x7FFFFFFF, mx = -1;
+        for (int t = lane; t < k; t += 64) {
+            const int key = acc.ord(L->sel_j[t]);
+            L->b_idx[t] = key;
+            mn = min(mn, key);
+            mx = max(mx, key);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { mn = min(mn, __shfl_xor(mn, off, 64)); mx = max(mx, __shfl_xor(mx, off, 64)); }
+        kmin = mn;
+        span = (unsigned)(mx - mn);
+        wave_lds_sync();
     }
-    wave_lds_sync();
-    const int kmin = L->scratch[62];
-    const unsigned span = (unsigned)(L->scratch[63] - kmin);
     if (span < 32u * KNN_BINS) {
         // the keys are distinct original indices: rank = number of set bits below the key's bit in a bitmap of the span
         // (L->hist is free once the selection is over); per-word exclusive prefixes fit a byte (rank < k <= 256)
@@ -470,12 +505,7 @@ __device__ __forceinline__ void sort_selected_by_index(WaveLds* L, const Acc& ac
         const uint4 w = *reinterpret_cast<const uint4*>(&bits[4 * lane]);
         const int c0 = __popc(w.x), c1 = __popc(w.y), c2 = __popc(w.z), c3 = __popc(w.w);
         const int s = c0 + c1 + c2 + c3;
-        int incl = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
+        int incl = wave_incl_scan_i(s);
         const unsigned e0 = (unsigned)(incl - s), e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
         reinterpret_cast<unsigned*>(L->rank_pre)[lane] = (e0 & 255u) | ((e1 & 255u) << 8) | ((e2 & 255u) << 16) | ((e3 & 255u) << 24);
         wave_lds_sync();
@@ -569,6 +599,7 @@ __device__ __forceinline__ void normal_flush_block(PT* pend, const Acc& acc, flo
 
 template <class Acc>
 struct NormalConsumer {
+    static constexpr bool WANTS_INNER = false;
     float4* normals;
     Acc acc;
     WaveLds* L;
@@ -649,6 +680,7 @@ __device__ __forceinline__ int clamp_bin11(int h) { return h < 0 ? 0 : (h >= 11 
 
 template <class Acc>
 struct SpfhConsumer {
+    static constexpr bool WANTS_INNER = false;
     const float4* normals;   // original order
     Acc acc;
     unsigned char* spfh_cnt; // [N][36] integer SPFH histograms
@@ -712,6 +744,10 @@ struct SpfhConsumer {
 #define NP_SLOTS_FUSED 8        // 80.9 KiB per workgroup with the 2 560-point tile: two workgroups per CU still fit
 template <class Acc>
 struct ListNormalConsumer {
+    // tile_select_guess marks the normal's own neighbours (the <= kn nearest inside rn2) while it selects the list: they fall out of the
+    // same histogram, so finish() need not find them again (its 64-bin histogram and rank loops were 4 300 of a query's 24 000 clocks)
+    static constexpr bool WANTS_INNER = true;
+    bool flagged = false;    // accept_in() was used: bit 31 of the stored d2 marks an inner neighbour
     typedef NormalPendingT<NP_SLOTS_FUSED> PT;
     float4* normals;         // out, original order
     Acc acc;
@@ -736,10 +772,61 @@ struct ListNormalConsumer {
         }
         ncount += __popcll(m);
     }
-    __device__ void finish(int k) {
+    __device__ void accept_in(bool sel, int j, float d2, bool inner) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int pos = ncount + __popcll(m & ((1ull << lane) - 1ull));
+            L->sel_j[pos] = j;
+            L->sel_d2[pos] = __uint_as_float(__float_as_uint(d2) | (inner ? 0x80000000u : 0u));
+        }
+        ncount += __popcll(m);
+        flagged = true;
+    }
+    __device__ void finish_flagged(int k) {
         const int lane = threadIdx.x & 63;
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        sort_selected_by_index<true>(L, acc, k);                  // b_j: handles, b_bits: d2 bits | inner flag, ascending original index
+        const bool immediate = P == nullptr;
+        const int slot = immediate ? 0 : P->n;
+        int kq = 0;
+        for (int t0 = 0; t0 < k; t0 += 64) {
+            const int t = t0 + lane;
+            const bool v = t < k;
+            const unsigned bits = v ? L->b_bits[t] : 0u;
+            const int h = v ? L->b_j[t] : 0;
+            if (v) {
+                nbr_idx[(int64_t)qi * K + t] = acc.ord(h);
+                nbr_d2[(int64_t)qi * K + t] = __uint_as_float(bits & 0x7FFFFFFFu);
+            }
+            const bool member = v && (bits >> 31) != 0u;
+            const unsigned long long mm = __ballot(member);
+            if (member) {
+                const int pos = kq + __popcll(mm & lt_mask);
+                if (immediate) L->b_idx[pos] = h;
+                else P->h[slot][pos] = (unsigned short)h;
+            }
+            kq += __popcll(mm);
+        }
+        if (lane == 0) nbr_cnt[qi] = k;
+        if (immediate) {
+            wave_lds_sync();
+            if (lane == 0) normal_solve(acc, L->b_idx, kq, qi, normals);
+        } else {
+            if (lane == 0) { P->qi[slot] = qi; P->k[slot] = kq; P->n = slot + 1; }
+            if (slot + 1 == PT::SLOTS) normal_flush(P, acc, normals);
+            else wave_lds_sync();
+        }
+    }
+    __device__ void finish(int k) {
+        if (flagged) { finish_flagged(k); return; }
+        const int lane = threadIdx.x & 63;
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#ifdef KNN_LAB_CLK
+        long long _clk_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
         sort_selected_by_index<true>(L, acc, k);                  // b_j: handles, b_bits: d2 bits, ascending original index
+        KNN_CLK(13);
         int n_in = 0;
         for (int t0 = 0; t0 < k; t0 += 64) {
             const int t = t0 + lane;
@@ -752,6 +839,7 @@ struct ListNormalConsumer {
             n_in += __popcll(__ballot(v && __uint_as_float(bits) < rn2));
         }
         if (lane == 0) nbr_cnt[qi] = k;
+        KNN_CLK(14);
         // ---- the normal's neighbours
         int b30 = 64, need = 0, popb = 0;
         const float nscale = 64.0f / rn2;
@@ -766,12 +854,7 @@ struct ListNormalConsumer {
             }
             wave_lds_sync();
             const int c = nh[lane];
-            int incl = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
+            int incl = wave_incl_scan_i(c);
             const unsigned long long m = __ballot(incl >= kn);
             b30 = __ffsll((long long)m) - 1;
             need = kn - __shfl(incl - c, b30, 64);
@@ -818,6 +901,7 @@ struct ListNormalConsumer {
             }
             kq += __popcll(mm);
         }
+        KNN_CLK(15);
         if (immediate) {
             wave_lds_sync();
             if (lane == 0) normal_solve(acc, L->b_idx, kq, qi, normals);
@@ -831,6 +915,7 @@ struct ListNormalConsumer {
 
 template <class Acc>
 struct GradConsumer {
+    static constexpr bool WANTS_INNER = false;
     const float4* normals;
     Acc acc;
     float4* grad;
@@ -899,12 +984,227 @@ struct GradConsumer {
 #ifdef KNN_LAB_STATS
 __device__ int knn_lab_stats[8];
 #endif
+
+// Round 3 fast path of tile_select: with a GUESS of the squared distance of the query's max_nn-th neighbour (the previous query of this
+// wave -- a neighbour in the same tile -- plus a margin) ONE pass over the staged candidates collects those closer than the guess (two
+// ballots and two LDS stores per 64 candidates: no histogram, no bins, no atomics in the pass that touches every candidate; it was 8 200
+// of a query's 24 000 clocks).  The list then holds every staged candidate with d2 < guess; when it has at least max_nn entries (and at
+// most the 256 the list holds) the max_nn nearest are among them -- anything outside is strictly farther -- and are selected from the
+// list alone through a 256-bin histogram of the LIST over [0, guess): the same candidates, the same (d2 bits, original index) order as
+// the two-pass selection below.  Returns 1 = done, 0 = not provable from the staged cube (the query joins the grid walk), -1 = the
+// guess was too small or too large (the caller runs the two-pass selection, which also renews the guess).
+template <class TL, class Consumer>
+__device__ int tile_select_guess(const TL& T, int total, const float4 q, float cover2, float r2, int max_nn, WaveLds* L, Consumer& cons, float& gthr) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float thr = fminf(gthr, r2);
+#ifdef KNN_LAB_CLK
+    long long _clk_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    int ccount = 0, in_ball = 0;
+    // 128 candidates per step, both LDS reads of the NEXT step in flight while this one is evaluated (the pass is a chain of LDS round
+    // trips otherwise: two waves per SIMD do not hide them)
+    const int last = total - 1;
+    float4 pa = T.pts[min(lane, last)], pb = T.pts[min(lane + 64, last)];
+#pragma unroll 1
+    for (int t0 = 0; t0 < total; t0 += 128) {
+        const float4 p0 = pa, p1 = pb;
+        pa = T.pts[min(t0 + 128 + lane, last)];
+        pb = T.pts[min(t0 + 192 + lane, last)];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + 64 * h + lane;
+            const float4 p = h ? p1 : p0;
+            const float d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
+            const bool valid = t < total;
+            in_ball += __popcll(__ballot(valid && d2 < cover2));
+            const bool col = valid && d2 < thr;
+            const unsigned long long mc = __ballot(col);
+            if (col) {
+                const int pos = ccount + __popcll(mc & lt_mask);
+                if (pos < KNN_CAPB) { L->b_j[pos] = t; L->b_bits[pos] = __float_as_uint(d2); }
+            }
+            ccount += __popcll(mc);
+        }
+    }
+    KNN_CLK(8);
+    if (cover2 != INFINITY && in_ball < max_nn) return 0;
+    if (ccount > KNN_CAPB || (ccount < max_nn && thr < r2)) return -1;
+    wave_lds_sync();
+    const int k = ccount < max_nn ? ccount : max_nn;
+    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the list, four entries per lane
+    unsigned eb[KNN_CAPB / 64];
+    int et[KNN_CAPB / 64];
+#pragma unroll
+    for (int u = 0; u < KNN_CAPB / 64; ++u) {
+        const int e = lane + 64 * u;
+        eb[u] = e < ccount ? L->b_bits[e] : 0xFFFFFFFFu;
+        et[u] = e < ccount ? L->b_j[e] : 0;
+    }
+    if (ccount <= max_nn) {                         // (thr == r2 here: the list is every staged candidate in radius)
+        cons.begin(k);                              // (a consumer with an inner set finds it itself on this rare path)
+#pragma unroll
+        for (int u = 0; u < KNN_CAPB / 64; ++u) cons.accept(lane + 64 * u < ccount, et[u], none, __uint_as_float(eb[u]));
+        cons.finish(k);
+        return 1;
+    }
+    const float lscale = (float)KNN_BINS / thr;
+    int ebin[KNN_CAPB / 64];
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 64; ++t) L->hist[lane * (KNN_BINS / 64) + t] = 0;
+    wave_lds_sync();
+#pragma unroll
+    for (int u = 0; u < KNN_CAPB / 64; ++u) {
+        const bool v = lane + 64 * u < ccount;
+        ebin[u] = v ? (int)fminf(__uint_as_float(eb[u]) * lscale, (float)(KNN_BINS - 1)) : KNN_BINS;
+        if (v) atomicAdd(&L->hist[ebin[u]], 1);
+    }
+    wave_lds_sync();
+    int hb[KNN_BINS / 64];
+    int s = 0;
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 64; ++t) { hb[t] = L->hist[lane * (KNN_BINS / 64) + t]; s += hb[t]; }
+    int incl = wave_incl_scan_i(s);
+    int bstar, n_below, pop;
+    {
+        const unsigned long long m = __ballot(incl >= max_nn);
+        const int Lc = __ffsll((long long)m) - 1;
+        int bin_here = 0, my_below = 0, my_pop = 0;
+        int run = incl - s;
+#pragma unroll
+        for (int t = 0; t < KNN_BINS / 64; ++t) {
+            if (my_pop == 0 && run + hb[t] >= max_nn) { bin_here = lane * (KNN_BINS / 64) + t; my_below = run; my_pop = hb[t]; }
+            run += hb[t];
+        }
+        bstar = __shfl(bin_here, Lc, 64);
+        n_below = __shfl(my_below, Lc, 64);
+        pop = __shfl(my_pop, Lc, 64);
+    }
+    // The inner set of a consumer that wants one (the normal's <= kn nearest inside rn2): {d2 < rn2} is a prefix of the (d2, index) order
+    // and so is the selection, hence n_in = min(k, list entries inside rn2); when n_in <= kn every selected entry inside rn2 belongs to
+    // it, otherwise the kn first of the order do: the bins below the one that holds the kn-th entry + that bin's entries by rank.
+    bool inner[KNN_CAPB / 64];
+    bool use_flags = false;
+    if constexpr (Consumer::WANTS_INNER) {
+        const float rn2 = cons.rn2;
+        const int kn = cons.kn;
+        int n_in_list = 0;
+#pragma unroll
+        for (int u = 0; u < KNN_CAPB / 64; ++u) {
+            inner[u] = lane + 64 * u < ccount && __uint_as_float(eb[u]) < rn2;
+            n_in_list += __popcll(__ballot(inner[u]));
+        }
+        use_flags = true;
+        if ((n_in_list < k ? n_in_list : k) > kn) {
+            const unsigned long long m = __ballot(incl >= kn);
+            const int Lc = __ffsll((long long)m) - 1;
+            int bin_here = 0, my_below = 0, my_pop = 0;
+            int run = incl - s;
+#pragma unroll
+            for (int t = 0; t < KNN_BINS / 64; ++t) {
+                if (my_pop == 0 && run + hb[t] >= kn) { bin_here = lane * (KNN_BINS / 64) + t; my_below = run; my_pop = hb[t]; }
+                run += hb[t];
+            }
+            const int b30 = __shfl(bin_here, Lc, 64);
+            const int need30 = kn - __shfl(my_below, Lc, 64);
+            const int pop30 = __shfl(my_pop, Lc, 64);
+            if (pop30 > 64) use_flags = false;          // (the consumer finds its inner set itself)
+            else {
+                // the kn-th entry's bin: its entries by (d2 bits, original index), parked in the idle sort scratch
+                int c30 = 0;
+#pragma unroll
+                for (int u = 0; u < KNN_CAPB / 64; ++u) {
+                    const bool pk = ebin[u] == b30;
+                    const unsigned long long mp = __ballot(pk);
+                    if (pk) {
+                        const int pos = c30 + __popcll(mp & lt_mask);
+                        L->rank_pre[pos] = (int)eb[u];
+                        L->scratch[pos] = T.ord[et[u]];
+                    }
+                    c30 += __popcll(mp);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int u = 0; u < KNN_CAPB / 64; ++u) {
+                    if (ebin[u] < b30) inner[u] = true;
+                    else if (ebin[u] > b30) inner[u] = false;
+                    else {
+                        const int mi = T.ord[et[u]];
+                        int rank = 0;
+                        for (int w = 0; w < pop30; ++w) {
+                            const unsigned ub = (unsigned)L->rank_pre[w];
+                            rank += (ub < eb[u] || (ub == eb[u] && L->scratch[w] < mi)) ? 1 : 0;
+                        }
+                        inner[u] = rank < need30;
+                    }
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+    KNN_CLK(9);
+    cons.begin(k);
+    // entries below the threshold bin go to the consumer; the threshold bin's entries are parked at the head of the list arrays (every
+    // lane holds its entries in registers by now)
+    int bcount = 0;
+#pragma unroll
+    for (int u = 0; u < KNN_CAPB / 64; ++u) {
+        if constexpr (Consumer::WANTS_INNER) {
+            if (use_flags) cons.accept_in(ebin[u] < bstar, et[u], __uint_as_float(eb[u]), inner[u]);
+            else cons.accept(ebin[u] < bstar, et[u], none, __uint_as_float(eb[u]));
+        } else
+        cons.accept(ebin[u] < bstar, et[u], none, __uint_as_float(eb[u]));
+        const bool park = ebin[u] == bstar;
+        const unsigned long long m = __ballot(park);
+        if (park) {
+            const int pos = bcount + __popcll(m & lt_mask);
+            L->b_bits[pos] = eb[u];
+            L->b_idx[pos] = T.ord[et[u]];
+            bool fl = false;
+            if constexpr (Consumer::WANTS_INNER) fl = use_flags && inner[u];
+            L->b_j[pos] = et[u] | (fl ? 0x40000000 : 0);        // (bit 30: inner flag of a parked entry)
+        }
+        bcount += __popcll(m);
+    }
+    KNN_CLK(10);
+    const int need = max_nn - n_below;
+    wave_lds_sync();
+    for (int e0 = 0; e0 < pop; e0 += 64) {
+        const int e = e0 + lane;
+        const bool v = e < pop;
+        const unsigned mb = v ? L->b_bits[e] : 0xFFFFFFFFu;
+        const int mi = v ? L->b_idx[e] : 0x7FFFFFFF;
+        int rank = 0;
+        for (int u = 0; u < pop; ++u) {
+            const unsigned ub = L->b_bits[u];
+            const int ui = L->b_idx[u];
+            rank += (ub < mb || (ub == mb && ui < mi)) ? 1 : 0;
+        }
+        const int hj = v ? L->b_j[e] : 0;
+        if constexpr (Consumer::WANTS_INNER) {
+            if (use_flags) cons.accept_in(v && rank < need, hj & 0x3FFFFFFF, __uint_as_float(mb), (hj & 0x40000000) != 0);
+            else cons.accept(v && rank < need, hj & 0x3FFFFFFF, none, __uint_as_float(mb));
+        } else
+        cons.accept(v && rank < need, hj & 0x3FFFFFFF, none, __uint_as_float(mb));
+    }
+    KNN_CLK(11);
+    // next guess: the upper edge of the threshold bin + a margin (a 30-neighbour search has 8x head-room in the 256-entry list)
+    gthr = fminf(r2, (float)(bstar + 1) / lscale * (max_nn * 4 <= KNN_CAPB ? 2.0f : 1.3f));
+    cons.finish(k);
+    KNN_CLK(12);
+    return 1;
+}
+
 template <class TL, class Consumer>
 __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2, float r2, int max_nn, WaveLds* L, Consumer& cons, int& gbin) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float bscale = (float)KNN_BINS / r2;
     auto bin_of = [&](float d2) { int b = (int)(d2 * bscale); return b > KNN_BINS - 1 ? KNN_BINS - 1 : b; };
+#ifdef KNN_LAB_CLK
+    long long _clk_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int t = 0; t < KNN_BINS / 64; ++t) L->hist[lane * (KNN_BINS / 64) + t] = 0;
     wave_lds_sync();
@@ -935,16 +1235,12 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
         ccount += __popcll(mc);
     }
     wave_lds_sync();
+    KNN_CLK(8);
     int hb[KNN_BINS / 64];
     int s = 0;
 #pragma unroll
     for (int t = 0; t < KNN_BINS / 64; ++t) { hb[t] = L->hist[lane * (KNN_BINS / 64) + t]; s += hb[t]; }
-    int incl = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
+    int incl = wave_incl_scan_i(s);
     const int cnt = __shfl(incl, 63, 64);
     if (cover2 != INFINITY && in_ball < max_nn) return false;
     const int excl = incl - s;
@@ -969,6 +1265,7 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
         gbin = min(KNN_BINS - 1, bstar + (max_nn * 4 <= KNN_CAPB ? bstar : (bstar >> KNN_GUESS_SHIFT)) + 2);
     }
     cons.begin(k);
+    KNN_CLK(9);
     int bcount = 0;
     const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool from_list = !select_all && bstar <= guess && ccount <= KNN_CAPB;
@@ -1018,6 +1315,7 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
             bcount += __popcll(m);
         }
     }
+    KNN_CLK(10);
     if (!select_all) {
         // the boundary bin: an entry is selected when fewer than `need` entries precede it in (d2 bits, original index) order
         const int need = max_nn - n_below;
@@ -1037,14 +1335,16 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
             cons.accept(sel, v ? L->b_j[e] : 0, none, __uint_as_float(mb));
         }
     }
+    KNN_CLK(11);
     cons.finish(k);
+    KNN_CLK(12);
     return true;
 }
 
 // Workgroup per tile: stage the neighbourhood, then every wavefront takes queries of the tile in turn.  need_pop[rho] = candidates
 // the staging cube of reach rho should hold for the ball inside it to contain max_nn of them (host: 1.15 max_nn (ts + 2 rho)^2 /
 // (pi rho^2)); the reach grows from 2 until it does, the cube fills the LDS budget or covers the whole radius.
-struct NeedPop { float v[8]; int rho_start; };
+struct NeedPop { float v[8]; int rho_start; int guess; };       // guess: tile_select_guess on (0: IBL_KNN_NOGUESS=1, the two-pass selection only)
 
 template <int TS, class TL, class Factory>
 __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int max_nn, const NeedPop& need_pop, int* __restrict__ fb_list,
@@ -1054,6 +1354,9 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     if (tile >= g.n_tiles) return;
+#ifdef KNN_LAB_CLK
+    long long _clk_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
     int lo = 0, hi = g.n_seg;                      // the segment whose tile range holds `tile`
     if (g.tile_seg) lo = g.tile_seg[tile];
     else
@@ -1085,6 +1388,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     }
     __syncthreads();
     const int nq = T.q_off[qrows];
+    KNN_CLK(0);
     if (nq == 0) return;
 
     int reach_max = (int)ceilf(radius * sg.inv);
@@ -1110,12 +1414,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
             int v[3], sum = 0;
 #pragma unroll
             for (int u = 0; u < 3; ++u) { const int r = 3 * lane + u; v[u] = r < nrows ? T.row_off[r + 1] : 0; sum += v[u]; }
-            int incl = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
+            int incl = wave_incl_scan_i(sum);
             int run = incl - sum;
             if (lane == 0) T.row_off[0] = 0;
 #pragma unroll
@@ -1131,6 +1430,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
         ++rho;
     }
     const float cellw = 1.0f / sg.inv;
+    KNN_CLK(1);
     if (staged) {
         const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
         for (int t = tid; t < total; t += 256) {
@@ -1145,6 +1445,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
         }
     }
     __syncthreads();
+    KNN_CLK(2);
     // faces of the staging cube (none where it reaches the cloud's bounds: nothing lies beyond), pulled in by the rounding margin of
     // the cell index
     const float mgn = 1e-3f * cellw;
@@ -1155,12 +1456,15 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     typename Factory::Pending* P = &pend[wave];
     if (lane == 0) P->n = 0;
     wave_lds_sync();
-    const TileAcc tacc{T.pts, T.ord};
+    // original-index range of the tile's segment (points are sorted by (segment, cell): a segment's sorted positions are its indices)
+    const int key_base = g.cell_start[sg.cell_base];
+    const TileAcc tacc{T.pts, T.ord, key_base, g.cell_start[sg.cell_base + sg.nx * sg.ny * sg.nz] - key_base};
     // threshold-bin guess carried from query to query of this wave.  To start (a tile holds ~9 queries, so the four waves' first
     // queries are 4 of 9): a pilot -- the whole workgroup histograms the staged candidates around the tile's middle query (five steps
     // of 256 threads) and the bin that holds its max_nn-th neighbour, + the margin, seeds every wave.  A guess that is too small or
     // too large only costs that query the full second pass.
     int gbin = -1;
+    float gthr = -1.0f;                            // round 3: the guess as a squared distance (tile_select_guess)
     if (staged && nq > 4) {
         int* ph = wl[0].hist;                          // idle until the first query
         __shared__ int pilot_bin;
@@ -1181,12 +1485,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
             int hb4[KNN_BINS / 64], sum = 0;
 #pragma unroll
             for (int u = 0; u < KNN_BINS / 64; ++u) { hb4[u] = ph[lane * (KNN_BINS / 64) + u]; sum += hb4[u]; }
-            int incl = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
+            int incl = wave_incl_scan_i(sum);
             const unsigned long long m = __ballot(incl >= max_nn);
             if (lane == 0) pilot_bin = -1;
             if (m != 0ull && lane == __ffsll((long long)m) - 1) {
@@ -1201,29 +1500,56 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
         }
         __syncthreads();
         const int pb = pilot_bin;
-        if (pb >= 0) gbin = min(KNN_BINS - 1, pb + (max_nn * 4 <= KNN_CAPB ? pb : (pb >> KNN_GUESS_SHIFT)) + 2);
+        if (pb >= 0) {
+            gbin = min(KNN_BINS - 1, pb + (max_nn * 4 <= KNN_CAPB ? pb : (pb >> KNN_GUESS_SHIFT)) + 2);
+            gthr = fminf(r2, (float)(gbin + 1) / bscale);
+        }
         __syncthreads();                               // wl[0].hist is wave 0's again
     }
+    const bool use_guess = need_pop.guess != 0;
+    KNN_CLK(3);
+#ifdef KNN_LAB_CLK
+    if (tid == 0) { atomicAdd(&knn_lab_clk[6], 1ull); atomicAdd(&knn_lab_clk[7], (unsigned long long)nq); }
+#endif
     int run_r = 0;
+    const int sny = y1 - y0 + 1;
     for (int qk = wave; qk < nq; qk += 4) {
         while (qk >= T.q_off[run_r + 1]) ++run_r;
         const int jq = T.q_b[run_r] + (qk - T.q_off[run_r]);
-        const int qi = g.order[jq];
+        // a query is a point of the tile, and the tile lies inside its staged cube: the point and its original index come from LDS (the two
+        // dependent global loads per query were ~15 % of a tile's time with two waves per SIMD to hide them)
+        int qi;
+        float4 q;
+        if (staged) {
+            const int sr = (cz0 + run_r / qny - z0) * sny + (cy0 + run_r % qny - y0);
+            const int ts_ = T.row_off[sr] + (jq - T.row_b[sr]);
+            qi = T.ord[ts_];
+            q = T.pts[ts_];
+        } else {
+            qi = g.order[jq];
+            q = g.sorted_pts[jq];
+        }
         if (qi < q_lo || qi >= q_hi) continue;
-        const float4 q = g.sorted_pts[jq];
         bool done = false;
         if (staged) {
             float cover = fminf(fminf(q.x - fx0, fx1 - q.x), fminf(fminf(q.y - fy0, fy1 - q.y), fminf(q.z - fz0, fz1 - q.z)));
             if (cover < 0.f) cover = 0.f;
             const float cover2 = cover >= radius ? INFINITY : cover * cover;
             auto cons = fac.template make<TileAcc>(qi, q, L, tacc, P);
-            done = tile_select(T, total, q, cover2, r2, max_nn, L, cons, gbin);
+            int fast = -1;
+            if (use_guess && gthr > 0.0f) fast = tile_select_guess(T, total, q, cover2, r2, max_nn, L, cons, gthr);
+            if (fast < 0) {
+                done = tile_select(T, total, q, cover2, r2, max_nn, L, cons, gbin);
+                if (done && gbin >= 0) gthr = fminf(r2, (float)(gbin + 1) * r2 / (float)KNN_BINS);
+            } else done = fast == 1;
         }
         // not provable from the staged cube (sparse spot, LDS budget, boundary-bin overflow): the query joins the list of the
         // per-query grid walk that runs after this kernel (ibl_knn_list_kernel)
         if (!done && lane == 0) fb_list[atomicAdd(fb_count, 1)] = jq;
     }
+    KNN_CLK(4);
     fac.flush_block(pend, tacc);            // the queries still parked (normals)
+    KNN_CLK(5);
 }
 
 struct NormalFactory {
@@ -1429,6 +1755,8 @@ static NeedPop need_pop_table(int max_nn, int ts) {
     for (int rho = 1; rho < 8; ++rho)
         np.v[rho] = (float)(ibl_knn_safety() * max_nn * (ts + 2.0 * rho) * (ts + 2.0 * rho) / (3.14159265358979 * rho * rho));
     np.rho_start = ibl_knn_rho();
+    const char* e = getenv("IBL_KNN_NOGUESS");          // diagnostics, read per call: the tests compare both selections bit for bit
+    np.guess = (e && atoi(e)) ? 0 : 1;
     return np;
 }
 
@@ -1450,6 +1778,17 @@ static int launch_knn(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, c
         else if (g.ts == 4) hipLaunchKernelGGL((ibl_knn_tile_kernel<4, 1024, Factory>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
         else return ibl_set_error(IBL_ERR_INTERNAL, "k-NN tiles of %d^3 cells are not built", g.ts);
         IBL_LAUNCH_CHECK();
+#ifdef KNN_LAB_CLK
+        { unsigned long long h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(knn_lab_clk), sizeof(h));
+          const double nt = (double)std::max<unsigned long long>(h[6], 1);
+          fprintf(stderr, "[knn-clk] k=%d ts=%d tiles with queries %llu (%.1f queries each): clocks (100 MHz ticks) per tile: query rows %.0f, rho loop %.0f, staging %.0f, "
+                  "pilot %.0f, queries(wave 0) %.0f, flush %.0f\n", max_nn, g.ts, h[6], (double)h[7] / nt, h[0] / nt, h[1] / nt, h[2] / nt, h[3] / nt, h[4] / nt, h[5] / nt);
+          const double nq0 = (double)h[7] / 4.0;         // queries of wave 0
+          fprintf(stderr, "[knn-clk]   per query of wave 0: pass 1 %.0f, threshold %.0f, pass 2 %.0f, boundary rank %.0f, consumer finish %.0f\n", h[8] / nq0, h[9] / nq0,
+                  h[10] / nq0, h[11] / nq0, h[12] / nq0);
+          fprintf(stderr, "[knn-clk]   consumer finish: index sort %.0f, list write %.0f, inner selection %.0f\n", h[13] / nq0, h[14] / nq0, h[15] / nq0);
+          unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(knn_lab_clk), z, sizeof(z)); }
+#endif
 #ifdef KNN_LAB_STATS
         { int h[8]; (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(knn_lab_stats), sizeof(h)); fprintf(stderr, "[knn-lab] k=%d queries %d from_list %d select_all %d guess_low %d overflow %d\n", max_nn, h[0], h[1], h[2], h[3], h[4]); int z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(knn_lab_stats), z, sizeof(z)); }
 #endif

@@ -99,3 +99,26 @@ def test_fused_normals_and_feature_search_equals_the_two_searches(ctx, monkeypat
     assert ctx.status() == 0
     assert torch.equal(got.normals[:b.n], ref.normals[:b.n]) and torch.equal(got.fpfh[:b.n], ref.fpfh[:b.n])
     assert torch.equal(n1, n2) and torch.equal(f1, f2)
+
+
+def test_guess_threshold_selection_equals_the_two_pass_selection(ctx, monkeypatch):
+    """round 3: the tile search collects the candidates below a GUESS of the k-th neighbour's distance in one pass and selects from that
+    list (tile_select_guess); IBL_KNN_NOGUESS=1 runs the two-pass histogram selection for every query: neighbour sets, normals, FPFH
+    and colour gradients must agree bit for bit -- dense, sparse, tiny and two-object clouds alike"""
+    from ibloc_amd.registration import CloudBatch, instance_features_batch, normals_fpfh_batch
+    rng = np.random.default_rng(78)
+    cs = clouds([5000, 3000, 1200, 40, 3, 0], 11)
+    cs.append((rng.uniform(-0.05, 0.05, size=(3000, 3))).astype(np.float32))          # > 100 points inside every normal radius
+    cs.append(np.concatenate([cs[0][:2000] + np.float32([0.3, 0, 0]), cs[1][:2000]]))
+    ints = [rng.uniform(0, 1, size=len(c)).astype(np.float32) for c in cs]
+    b = CloudBatch.from_numpy(cs, ints)
+    got = instance_features_batch(ctx, b, 0.05, grad_radius=0.15)
+    n1, f1 = normals_fpfh_batch(ctx, b, 0.1, 30, 0.25, 100)
+    monkeypatch.setenv("IBL_KNN_NOGUESS", "1")
+    ref = instance_features_batch(ctx, b, 0.05, grad_radius=0.15)
+    n2, f2 = normals_fpfh_batch(ctx, b, 0.1, 30, 0.25, 100)
+    torch.cuda.synchronize()
+    assert ctx.status() == 0
+    assert torch.equal(got.normals[:b.n], ref.normals[:b.n]) and torch.equal(got.fpfh[:b.n], ref.fpfh[:b.n])
+    assert torch.equal(got.grad[:b.n], ref.grad[:b.n]) and torch.equal(got.fpfh_split[:b.n], ref.fpfh_split[:b.n])
+    assert torch.equal(n1, n2) and torch.equal(f1, f2)
