@@ -619,9 +619,15 @@ static int assign_frame_candidates(const uint16_t* val, const int32_t* idx, cons
     uint8_t complete[7];
     U.clear();
     for (int i = 0; i < Q; ++i) {
-        const int n = cnt[i];
+        int n = cnt[i];
         ents.resize(n);
         for (int e = 0; e < n; ++e) ents[e] = {half_bits_to_float(val[i * stride + e]), idx[i * stride + e]};
+        // A producer's two ends overlap when its thresholds fall into one tie class (a row of n_cols - S + 2 or more equal values: the
+        // zero-padded rows every shard matches, degenerate embeddings): both ends break ties by lower column first, so the same column
+        // can arrive twice.  Columns are counted once -- `complete` and the hole test below count columns, not list entries.
+        std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.c < y.c; });
+        ents.erase(std::unique(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.c == y.c; }), ents.end());
+        n = (int)ents.size();
         auto desc = [](const Ent& x, const Ent& y) { return x.v != y.v ? x.v > y.v : x.c < y.c; };
         auto asc = [](const Ent& x, const Ent& y) { return x.v != y.v ? x.v < y.v : x.c < y.c; };
         keep[i].clear();

@@ -114,3 +114,22 @@ def test_small_candidate_lists_fall_back_instead_of_guessing():
         v, j, n = candidates(aug, k_hi, k_lo, 1)
         got, exact = assign_candidates(v, j, n, [0], [Q], M, k_hi, k_lo, 4)
         assert (not exact[0]) or got[0] == full
+
+
+@pytest.mark.parametrize("M", [225, 226, 230, 300, 1000])
+def test_duplicate_columns_of_overlapping_ends_are_counted_once(M):
+    """a row whose hi and lo thresholds fall into ONE tie class (constant rows; zero-padded query rows of the sharded match): both ends of
+    the device selection break ties by lower index, so the two lists share columns (`keep[i].size()` counted them twice, which
+    could hide a hole).  The host must count columns once: never a wrong list, and constant rows just above the list size are not
+    mistaken for complete rows."""
+    rng = np.random.default_rng(M)
+    k_hi, k_lo, Q = 192, 32, 3
+    sims = np.full((Q, M), 0.5, dtype=np.float32)
+    sims[1] = rng.choice([0.5, 0.25], size=M)                   # two levels: both thresholds inside the 0.5 / 0.25 classes
+    sims[2, :5] = [0.9, 0.8, 0.7, -0.3, -0.6]                   # a few distinct entries + a constant remainder
+    aug = so._augment(sims)
+    v, j, n = candidates(aug, k_hi, k_lo, 1)
+    assert any(len(set(j[i, :n[i]].tolist())) < n[i] for i in range(Q)) or M <= k_hi + k_lo      # the lists really share columns
+    full = assign_batch(aug[None], [Q], 4)[0]
+    got, exact = assign_candidates(v, j, n, [0], [Q], M, k_hi, k_lo, 4)
+    assert (not exact[0]) or got[0] == full

@@ -132,3 +132,23 @@ def test_sharded_exchange_through_the_library_rccl_communicator_world_1():
     assert np.allclose(fit, [0.5, 1.0]) and np.allclose(rmse, [np.sqrt(0.1), np.sqrt(0.25)])
     comm.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("M", [226, 300, 10000])
+def test_constant_rows_through_the_device_selection_and_the_host_proof(M):
+    """constant / two-level rows: the device's two ends share columns (both break ties by lower index); the host counts columns once and
+    either proves the frame or reports it for the full-row search -- never a wrong list"""
+    from ibloc_amd.assign import assign_batch, assign_candidates
+    rng = np.random.default_rng(M)
+    Q, k_hi, k_lo = 3, 192, 32
+    aug = np.ones((Q, M + 1), dtype=np.float16)
+    aug[0, :M] = 0.5
+    aug[1, :M] = rng.choice([0.5, 0.25], size=M)
+    aug[2, :M] = 0.5
+    aug[2, :5] = [0.9, 0.8, 0.7, -0.3, -0.6]
+    val, idx, cnt = _select_dev(aug, M, k_hi, k_lo, base=0)
+    n = cnt.sum(axis=1).astype(np.int32)
+    assert len(set(idx[0, :n[0]].tolist())) < n[0]                 # the ends of a constant row overlap
+    full = assign_batch(aug[None], [Q], 4)[0]
+    got, exact = assign_candidates(val, idx, n, [0], [Q], M, k_hi, k_lo, 4)
+    assert (not exact[0]) or got[0] == full
