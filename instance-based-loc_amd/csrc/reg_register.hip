@@ -33,6 +33,13 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
 #ifndef ICP_CELL_DIV
 #define ICP_CELL_DIV 2.0     // cells of the ICP neighbour grid per correspondence distance (finer cells: fewer candidates per walk)
 #endif
+// ICP iteration from which a source point is searched by 8 lanes (ibl_icp_nn_group_kernel).  Measured per-launch times of the T
+// workload (us): thread per point 446 376 351 347 342 324 229 136 115 100 ... 85 (floor); eight lanes 411 186 106 80 65 ... 41 (floor)
+#ifndef ICP_GROUP_FROM
+#define ICP_GROUP_FROM 8
+#endif
+// (32 lanes per point from iteration 11 on measured 100 us per launch: the grid of 32x the blocks, nearly all of finished jobs, costs
+// more to schedule than the shorter walk saves)
 #define ICP_BPJ 8        // blocks per job in the ICP / evaluation reductions (each ends in a 29-value fp64 block reduction)
 #define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
 
@@ -815,6 +822,99 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
     }
     *d2out = bd;
     return best;
+}
+
+// The same search by a GROUP of LPQ lanes per query (tail iterations of the ICP, below): a lane takes four consecutive candidates of
+// every 4 * LPQ, so a row of n candidates costs n / (4 LPQ) dependent load rounds instead of n / 8, and the lanes of a group share
+// their best distance after every row for the pruning.  The group's result is the (d2, index) lexicographic minimum over its lanes:
+// the same neighbour as nn_within, whatever the order.
+template <int LPQ>
+__device__ __forceinline__ int nn_within_group(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, int sub, int best,
+                                               float* d2out) {
+    int reach = (int)ceilf(radius * sg.inv);
+    if (reach < 1) reach = 1;
+    const int cx = (int)floorf((qx - sg.minx) * sg.inv), cy = (int)floorf((qy - sg.miny) * sg.inv), cz = (int)floorf((qz - sg.minz) * sg.inv);
+    float bd = *d2out;            // this lane's best
+    float gbd = bd;               // the group's best distance (pruning bound)
+#pragma unroll
+    for (int off = 1; off < LPQ; off <<= 1) gbd = fminf(gbd, __shfl_xor(gbd, off, 64));
+    const int x0 = max(cx - reach, 0), x1 = min(cx + reach, sg.nx - 1);
+    const float csz = 1.0f / sg.inv, slack = 1e-4f * csz + 1e-6f;
+    auto scan_row = [&](int z, int y) {
+        const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
+        const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+        for (int jj = b + 4 * sub; jj < e; jj += 4 * LPQ) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = g.sorted_pts[min(jj + u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (jj + u >= e) break;
+                const float d2 = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+                if (d2 < bd) { bd = d2; best = g.order[jj + u]; }
+                else if (d2 == bd && best >= 0) { const int o = g.order[jj + u]; if (o < best) best = o; }
+            }
+        }
+        gbd = fminf(gbd, bd);
+#pragma unroll
+        for (int off = 1; off < LPQ; off <<= 1) gbd = fminf(gbd, __shfl_xor(gbd, off, 64));
+    };
+    if (x1 >= x0) {
+        const bool centre = cz >= 0 && cz < sg.nz && cy >= 0 && cy < sg.ny;
+        if (centre) scan_row(cz, cy);
+        for (int z = max(cz - reach, 0); z <= min(cz + reach, sg.nz - 1); ++z) {
+            const float zlo = sg.minz + (float)z * csz;
+            const float gz = fmaxf((qz < zlo ? zlo - qz : (qz > zlo + csz ? qz - zlo - csz : 0.0f)) - slack, 0.0f);
+            for (int y = max(cy - reach, 0); y <= min(cy + reach, sg.ny - 1); ++y) {
+                if (centre && z == cz && y == cy) continue;
+                const float ylo = sg.miny + (float)y * csz;
+                const float gy = fmaxf((qy < ylo ? ylo - qy : (qy > ylo + csz ? qy - ylo - csz : 0.0f)) - slack, 0.0f);
+                if (gz * gz + gy * gy > gbd) continue;          // (strictly larger than the group's best: ties are still compared)
+                scan_row(z, y);
+            }
+        }
+    }
+    *d2out = bd;
+    return best;
+}
+
+// Late ICP iterations: the jobs still running are the ones that do not converge (wrong assignments: sources with no target inside the
+// correspondence distance scan their whole 5 x 5 x 5 neighbourhood, ~1 000 candidates in ~125 dependent rounds), and with few jobs
+// left a launch is as long as one thread's walk (~90 us, 22 launches per batch).  Here LPQ lanes share a query.
+template <int LPQ>
+__global__ __launch_bounds__(256) void ibl_icp_nn_group_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ job_off, int J,
+                                                               const int* __restrict__ piece_off, const IcpState* __restrict__ st, float radius,
+                                                               float r2, int* __restrict__ nn_idx, float* __restrict__ nn_d2) {
+    const int j = blockIdx.y;
+    const IcpState& S = st[j];
+    if (S.done) return;
+    const int sub = threadIdx.x % LPQ;
+    const int p = job_off[j] + blockIdx.x * (256 / LPQ) + threadIdx.x / LPQ;
+    if (p >= job_off[j + 1]) return;                 // (whole groups leave together)
+    const int i = g.order[p];
+    const float4 s4 = pts[i];
+    double T[12], vs[3];
+    for (int t = 0; t < 12; ++t) T[t] = S.T[t];
+    xform_d(T, s4.x, s4.y, s4.z, vs);
+    float d2 = r2;
+    int best = -1;
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {
+        const int k = J + 3 * j + t;
+        if (piece_off[k + 1] > piece_off[k])      // (a lane keeps its own best from piece to piece; the group's best prunes)
+            best = nn_within_group<LPQ>(g, g.seg[k], (float)vs[0], (float)vs[1], (float)vs[2], radius, sub, best, &d2);
+    }
+    // (d2, index) minimum over the group; best = -1 (with d2 = r2) marks a lane that found nothing
+#pragma unroll
+    for (int off = 1; off < LPQ; off <<= 1) {
+        const float od = __shfl_xor(d2, off, 64);
+        const int ob = __shfl_xor(best, off, 64);
+        if (od < d2 || (od == d2 && ob >= 0 && (best < 0 || ob < best))) { d2 = od; best = ob; }
+    }
+    if (sub == 0) {
+        nn_idx[i] = best;
+        nn_d2[i] = d2;
+    }
 }
 
 // Thread per source point of every job: nearest target point under the job's current T.  Split from the accumulation so
@@ -1654,8 +1754,12 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         for (int j = 0; j < J; ++j) max_side = std::max(max_side, job_off[j + 1] - job_off[j]);
         const unsigned chunks = (unsigned)std::max(1, (max_side + 255) / 256);
         for (int it = 0; it <= max_iter; ++it) {
-            hipLaunchKernelGGL(ibl_icp_nn_kernel, dim3(chunks, J), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is, (float)max_dist_icp,
-                               (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
+            if (it < ICP_GROUP_FROM)
+                hipLaunchKernelGGL(ibl_icp_nn_kernel, dim3(chunks, J), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is, (float)max_dist_icp,
+                                   (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
+            else
+                hipLaunchKernelGGL(ibl_icp_nn_group_kernel<8>, dim3(chunks * 8, J), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is,
+                                   (float)max_dist_icp, (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
             IBL_LAUNCH_CHECK();
             hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, P, normals, grad, d_job_off, J, is, icp_nn, icp_d2,
                                colored ? 1 : 0, sqrt(lambda_geometric), sqrt(1.0 - lambda_geometric), partial);
