@@ -466,6 +466,31 @@ int ibl_evaluate_batch(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float* d
                        const int32_t* job_end, const double* T_global, int n_jobs, double threshold, double* rmse_out,
                        double* fitness_out, void* stream);
 
+/* Stage B of localise() for a batch of frames in ONE call (SURVEY 8b's fused driver; csrc/localise.hip): radius-outlier removal of
+ * every detected cloud and ordered compaction (object_memory/object_memory.py:992-998), the detections' instance features, one
+ * registration job per candidate assignment (:1020-1095), the global-frame transform of every job (:1096-1101), its whole-memory
+ * evaluation (:1104) and the winner of every frame (highest whole-memory fitness, the first on ties, :1111-1114).  Everything is
+ * the library's own stage entry points composed on the host -- the results are those of calling ibl_radius_outlier_batch,
+ * ibl_instance_features_batch, ibl_register_batch_cached and ibl_evaluate_batch in turn, bit for bit.
+ *   det_pts4 / det_off_dev / det_off_host: the RAW detected clouds, segments in frame order, q_per_frame [HOST][n_frames] of them per
+ *   frame (<= 7 each); assn [HOST][n_frames][max_assn][6] = up to three (detection within its frame, GLOBAL memory instance) pairs
+ *   per assignment, assn_len [HOST][n_frames][max_assn] pairs used, assn_count [HOST][n_frames] -- the output layout of
+ *   ibl_assign_batch / ibl_assign_candidates; mem_*: the memory pool, its resident instance features and its spatial hash.
+ * Outputs (HOST; the call synchronises): clean_off_host [n_det_seg + 1] offsets of the cleaned clouds, *n_jobs_out = J (jobs in
+ * frame order, a frame's jobs in assignment order; J <= max_jobs = the capacity of the per-job arrays), T_out .. reuse_stats_out as
+ * ibl_register_batch_cached, T_global_out [J][16], full_rmse_out / full_fitness_out [J], best_out [n_frames] = winning assignment of
+ * the frame (index into its list) or -1 for a frame without assignments. */
+int ibl_register_evaluate_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                                int n_det_seg, const int32_t* q_per_frame, int n_frames, const int32_t* assn, const int32_t* assn_len,
+                                const int32_t* assn_count, int max_assn, const float* mem_pts4, const int32_t* mem_off_dev,
+                                const int32_t* mem_off_host, int n_mem_seg, const ibl_instance_features* mem_features,
+                                const ibl_memgrid* grid, double voxel_size, double global_dist_factor, double local_dist_factor,
+                                double outlier_radius, int outlier_nb_points, double eval_threshold, uint64_t seed, uint32_t job_id_base,
+                                int64_t ransac_max_iter, int flags, int max_jobs, int32_t* clean_off_host, int32_t* n_jobs_out,
+                                double* T_out, double* rmse_out, double* fitness_out, double* means_out, double* T_ransac_out,
+                                int64_t* ransac_stats_out, int64_t* reuse_stats_out, double* T_global_out, double* full_rmse_out,
+                                double* full_fitness_out, int32_t* best_out, void* stream);
+
 /* Same, and additionally the squared distance of every transformed detected point to its nearest memory point within `threshold`
  * (+inf when there is none): d2_out [dev] floats, job j's points at offset sum_{i<j} (job_end[i] - job_begin[i]).  This is the
  * per-shard half of the sharded whole-memory evaluation of SURVEY 8(e): every rank evaluates against the memory points it owns, the

@@ -71,6 +71,9 @@ _SIGS = {
     "ibl_memgrid_build": (C.c_int, [vp, vp, C.c_int64, C.c_double, C.POINTER(vp), vp]),
     "ibl_memgrid_destroy": (C.c_int, [vp]),
     "ibl_evaluate_batch": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, vp, vp]),
+    "ibl_register_evaluate_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp,
+                                              C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_uint64, C.c_uint32,
+                                              C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ibl_evaluate_points": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, vp, vp, vp]),
     "ibl_dator_head_workspace_bytes": (C.c_int64, [C.c_int]),
     "ibl_dator_head_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int64, vp]),

@@ -29,7 +29,7 @@ from . import match
 from .assign import K_HI, K_LO, assign_batch, assign_candidates
 from .parallel import ShardExchange, shard_range, sharded_candidates
 from .registration import (CloudBatch, InstanceFeatures, MemGrid, RegContext, evaluate_batch, evaluate_points,
-                           instance_features_batch, radius_outlier_batch, register_batch)
+                           instance_features_batch, radius_outlier_batch, register_batch, register_evaluate_batch)
 
 IBL_ST_GRID_OVERFLOW = 1          # ibl_reg_ctx_status bits (include/ibloc.h)
 
@@ -126,6 +126,7 @@ class LocaliseEngine:
         self.k_hi, self.k_lo = int(k_hi), int(k_lo)
         self.reuse_features = True      # False: every assignment recomputes its features (same results, the reference's schedule)
         self.use_candidates = True      # False: the assignment search always runs on the full rows (what round 1 did)
+        self.fused_stage_b = True       # False: stage B as a sequence of library calls issued from Python (what rounds 1-2 did)
         self._pool_a = None             # stage-A worker of localise_stream
         self._pool_w = None             # lane threads of localise_concurrent
         self._lanes = []
@@ -465,6 +466,17 @@ class LocaliseEngine:
                 results[f].best = 0 if assns[f] else -1
             close_timings()
             return results
+        # ---- stage B in one library call (ibl_register_evaluate_batch, csrc/localise.hip): what the staged sequence below computes, bit
+        # for bit (tests/test_gpu_engine.py), without Python or torch between the launches.  The staged form remains for per-stage
+        # timings, for reuse_features = False and for sharded clouds (whose stages are separated by collectives).
+        if self.fused_stage_b and timings is None and self.route is None and self.reuse_features:
+            if not any(len(a) for a in assns):
+                return results
+            thr = eval_threshold if eval_threshold is not None else mem.eval_threshold
+            r = register_evaluate_batch(ctx, det, q_per_frame, assns, mem.clouds, mem.features(fpfh_voxel_size, fpfh_local_dist_factor), mem.grid,
+                                        fpfh_voxel_size, fpfh_global_dist_factor, fpfh_local_dist_factor, outlier_radius, outlier_nb_points, thr,
+                                        seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter, fixed_budget=ransac_fixed_budget)
+            return self._assemble(results, assns, row0, r["clean_off"], r, r["T_global"], r["full_rmse"], r["full_fitness"])
         # ---- clean the detected clouds (:992-998) ---------------------------------------------------
         keep = radius_outlier_batch(ctx, det, outlier_radius, outlier_nb_points)
         keepb = keep.bool()
@@ -521,10 +533,18 @@ class LocaliseEngine:
         else:
             full_rmse, full_fit = evaluate_batch(ctx, mem.grid, clean.pts4, jb, je, G, thr)     # :1104
         tick("evaluate")
-        # ---- selection + pose (:1111-1131) -----------------------------------------------------------
+        self._assemble(results, assns, row0, new_off_h, reg, G, full_rmse, full_fit)
+        tick("select")
+        close_timings()
+        return results
+
+    @staticmethod
+    def _assemble(results, assns, row0, new_off_h, reg, G, full_rmse, full_fit):
+        """selection + pose (:1111-1131) from the per-job arrays (frames in order, a frame's jobs in assignment order)"""
+        T, means = reg["T"], reg["means"]
         j = 0
         picked = []                          # (frame, first job, best job) of the frames that have assignments
-        for f in range(F):
+        for f in range(len(assns)):
             n_a = len(assns[f])
             if n_a == 0:
                 continue
@@ -547,6 +567,4 @@ class LocaliseEngine:
             t_fix = t + means[j0 + best, 1] - R @ means[j0 + best, 0]
             results[f] = FrameResult(np.concatenate((t_ref, q)), np.concatenate((t_fix, q)), assns[f], recs, best,
                                      int(new_off_h[row0[f + 1]] - new_off_h[row0[f]]))
-        tick("select")
-        close_timings()
         return results

@@ -239,6 +239,47 @@ def register_batch(ctx: RegContext, det: CloudBatch, mem: CloudBatch, job_src_se
                 reuse=reuse)
 
 
+def register_evaluate_batch(ctx: RegContext, det: CloudBatch, q_per_frame, assns, mem: CloudBatch, mem_features: InstanceFeatures, grid,
+                            voxel_size, global_dist_factor, local_dist_factor, outlier_radius=0.05, outlier_nb_points=8, eval_threshold=0.02,
+                            seed=0, job_id_base=0, ransac_max_iter=4000000, have_colors=True, center=True, fixed_budget=False):
+    """Stage B of localise() in one library call (`ibl_register_evaluate_batch`, csrc/localise.hip): outlier removal + compaction, the
+    detections' features, registration of every candidate assignment, whole-memory evaluation, winner per frame.  assns: per frame the
+    list of assignments [[det, mem], ...] (what the assignment search returns).  Returns a dict of host arrays: clean_off (S + 1), T, rmse,
+    fitness, means, T_ransac, ransac_stats, reuse, T_global, full_rmse, full_fitness (per job, frames in order) and best (per frame)."""
+    q = np.ascontiguousarray(q_per_frame, dtype=np.int32)
+    F = len(q)
+    max_assn = max(6, max((len(a) for a in assns), default=0))
+    assn = np.full((F, max_assn, 6), -1, dtype=np.int32)
+    alen = np.zeros((F, max_assn), dtype=np.int32)
+    acnt = np.zeros(F, dtype=np.int32)
+    for f, lst in enumerate(assns):
+        acnt[f] = len(lst)
+        for a, pairs in enumerate(lst):
+            alen[f, a] = len(pairs)
+            for t, (d, m) in enumerate(pairs):
+                assn[f, a, 2 * t], assn[f, a, 2 * t + 1] = d, m
+    J = int(acnt.sum())
+    Jc = max(J, 1)
+    clean_off = np.zeros(det.n_seg + 1, dtype=np.int32)
+    n_jobs = C.c_int32(0)
+    T = np.zeros((Jc, 16)); rmse = np.zeros(Jc); fit = np.zeros(Jc); means = np.zeros((Jc, 2, 3)); Tr = np.zeros((Jc, 16))
+    stats = np.zeros((Jc, 3), dtype=np.int64); reuse = np.zeros(6, dtype=np.int64)
+    G = np.zeros((Jc, 16)); frmse = np.zeros(Jc); ffit = np.zeros(Jc); best = np.full(max(F, 1), -1, dtype=np.int32)
+    flags = (REG_HAVE_COLORS if have_colors else 0) | (REG_CENTER if center else 0) | (REG_FIXED_BUDGET if fixed_budget else 0)
+    mf = mem_features.as_struct()
+    st = _lib.lib.ibl_register_evaluate_batch(
+        ctx.handle, det.pts4.data_ptr(), det.seg_off.data_ptr(), det.seg_off_host.ctypes.data, det.n_seg, q.ctypes.data, F, assn.ctypes.data,
+        alen.ctypes.data, acnt.ctypes.data, max_assn, mem.pts4.data_ptr(), mem.seg_off.data_ptr(), mem.seg_off_host.ctypes.data, mem.n_seg,
+        C.byref(mf), grid.handle, float(voxel_size), float(global_dist_factor), float(local_dist_factor), float(outlier_radius),
+        int(outlier_nb_points), float(eval_threshold), int(seed), int(job_id_base), int(ransac_max_iter), flags, Jc, clean_off.ctypes.data,
+        C.byref(n_jobs), T.ctypes.data, rmse.ctypes.data, fit.ctypes.data, means.ctypes.data, Tr.ctypes.data, stats.ctypes.data,
+        reuse.ctypes.data, G.ctypes.data, frmse.ctypes.data, ffit.ctypes.data, best.ctypes.data, _stream())
+    _lib.check(st, "ibl_register_evaluate_batch")
+    assert n_jobs.value == J
+    return dict(clean_off=clean_off, T=T[:J].reshape(J, 4, 4), rmse=rmse[:J], fitness=fit[:J], means=means[:J], T_ransac=Tr[:J].reshape(J, 4, 4),
+                ransac_stats=stats[:J], reuse=reuse, T_global=G[:J].reshape(J, 4, 4), full_rmse=frmse[:J], full_fitness=ffit[:J], best=best[:F])
+
+
 class MemGrid:
     """Persistent spatial hash over all memory points (lives in the context arena)."""
 

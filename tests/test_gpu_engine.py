@@ -111,6 +111,52 @@ def test_feature_reuse_does_not_change_results():
     ctx.close()
 
 
+def test_fused_stage_b_entry_equals_the_staged_sequence():
+    """`ibl_register_evaluate_batch` (SURVEY 8b's fused driver: outlier removal + compaction, detection features, registration, whole-memory
+    evaluation, winner per frame in ONE C-ABI call) against the same stages issued one library call at a time from Python: every
+    number of every FrameResult bit for bit; a frame without detections and an empty batch included; bad arguments rejected"""
+    from ibloc_amd import _lib
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+    from ibloc_amd.registration import CloudBatch, RegContext, register_evaluate_batch
+    from ibloc_amd.synth import SynthWorld
+    w = SynthWorld(12, pts_per_object=2500, E=2, D=32, seed=61, spacing=1.6)
+    rng = np.random.default_rng(63)
+    frames = [w.make_frame(rng, q=q, pts_per_object=2500) for q in (3, 1, 2)]
+    ctx = RegContext(6 << 30)
+    mem = MemoryShard(ctx, list(w.embeddings), w.points, colors=w.colors)
+    clouds = [c[0] for f in frames for c in f["clouds"]]
+    rnd = np.random.default_rng(1)
+    clouds[0] = np.concatenate([clouds[0], rnd.uniform(-3, 3, size=(50, 3))])           # stray points for the outlier removal
+    ints = [intensity_from_colors(c[1]) for f in frames for c in f["clouds"]]
+    ints[0] = np.concatenate([ints[0], np.zeros(50, np.float32)])
+    det = CloudBatch.from_numpy(clouds, ints)
+    emb = np.concatenate([f["det_emb"] for f in frames])
+    qs = [len(f["ids"]) for f in frames]
+    kw = dict(det_emb=emb, fpfh_voxel_size=0.05, fpfh_global_dist_factor=1.5, fpfh_local_dist_factor=1.5, seed=3, job_id_base=17)
+    eng = LocaliseEngine(mem, None)
+    fused = eng.localise_batch(det, qs, **kw)
+    eng.fused_stage_b = False
+    staged = eng.localise_batch(det, qs, **kw)
+    assert sum(len(r.records) for r in fused) > 6
+    for a, b in zip(fused, staged):
+        assert a.assignments == b.assignments and a.best == b.best and a.n_clean == b.n_clean
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.pose_corrected, b.pose_corrected)
+        for x, y in zip(a.records, b.records):
+            for k in ("T", "T_global", "ransac_stats", "detected_mean", "memory_mean"):
+                assert np.array_equal(x[k], y[k]), k
+            for k in ("rmse", "fitness", "full_rmse", "full_fitness"):
+                assert x[k] == y[k], k
+    assert fused[0].n_clean < sum(len(c) for c in clouds[:3])                          # the stray points were removed
+    # the entry itself: a frame without assignments gets best = -1, an out-of-range instance is rejected
+    mf = mem.features(0.05, 1.5)
+    r = register_evaluate_batch(ctx, det, qs, [fused[0].assignments, [], fused[2].assignments], mem.clouds, mf, mem.grid, 0.05, 1.5, 1.5, seed=3,
+                                job_id_base=17)
+    assert r["best"][1] == -1 and r["best"][0] == fused[0].best and len(r["T"]) == len(fused[0].assignments) + len(fused[2].assignments)
+    with pytest.raises(_lib.IblError):
+        register_evaluate_batch(ctx, det, qs, [[[[0, 999]]], [], []], mem.clouds, mf, mem.grid, 0.05, 1.5, 1.5)
+    ctx.close()
+
+
 def test_full_size_properties():
     """BASELINE configs[1] sizes (M = 1000 instances x 5000 points, E = 4, Q = 7): properties that need no oracle run --
     (1) batching: a frame localised alone equals the same frame inside a batch (same job ids -> same RANSAC draws);
