@@ -401,6 +401,12 @@ def main():
         for e in stage_roofs:
             e["ms_per_step"] = e.pop("ms") / n_extra
             e["work_per_step"] = e.pop("work") / n_extra
+        # stage B is one library call (ibl_register_evaluate_batch): its split comes from the library's stage timer
+        for key, name in (("outlier", "outlier (a9)"), ("det_features", "normals+FPFH (a11)"), ("feature_match", "feature match (a12)"),
+                          ("ransac", "RANSAC (a12)"), ("icp", "coloured ICP (a12)"), ("evaluate", "evaluate (a13)")):
+            for e in stage_roofs:
+                if e["stage"] == name:
+                    timings[key] = e["ms_per_step"]
         # SURVEY 8d's fixed-budget RANSAC figure: H hypotheses per job with the confidence exit off (never the product setting)
         if args.register and args.ransac_budget > 0 and not args.shard_clouds:
             prof.reset(enable=True)

@@ -49,6 +49,7 @@ struct GemmEpi {
     int accumulate;         // EPI_PATCH: x += alpha * acc instead of x = acc + bias + pos (second weight term of a two-term operand)
     float alpha;
     int algo_k;             // K the in-process timer counts as algorithmic (0: K itself; -1: none -- extra terms of a two-term operand are overhead, not model FLOPs)
+    int stagger;            // persistent grid: workgroup b sleeps (b % 4) * stagger * 64 clocks before its first tile (launch_gemm_cfg)
 };
 
 constexpr int GBK = 64;                 // K granule every caller guarantees (K % 64 == 0)
@@ -189,6 +190,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         }                                                                                          \
     } while (0)
     int tile = blockIdx.x;
+    if constexpr (PIPE) {
+        // Staggered start (residual epilogue only, set by the launcher): the workgroups of a persistent grid run in lockstep -- all K
+        // loops together (HBM nearly idle), then all fp32 read-modify-write epilogues together (HBM saturated at 5.8 TB/s, MFMA idle).
+        // Four phase groups, a quarter of a tile apart, spread the epilogue traffic over the whole launch.
+        if (epi.stagger > 0) {
+            const int ph = ((blockIdx.x >> 3) & 3) * epi.stagger;      // (blockIdx % 8 labels the XCD: every XCD gets all four phases)
+            for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     GEMM_SET_TILE(tile);
 #define GEMM_GLDS(buf, kt)                                                                                              \
     do {                                                                                                                \
@@ -582,9 +592,18 @@ static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw,
         }
         if (grid > cus * OCC) grid = cus * OCC;
     }
+    GemmEpi e2 = epi;
+    if (PIPE && EPI == EPI_RESID_F32 && grid < nwg) {
+        // lab only (IBL_GEMM_STAGGER = s_sleep(64) units per phase group): measured and rejected in round 3 -- proj 125 / 142 / 155 / 171 us
+        // and fc2 304 / 311 / 322 / 341 us at 0 / 3 / 6 / 10: the epilogue is not slowed by the other workgroups' epilogues, the delay is
+        // pure tail
+        static int stag = -2;
+        if (stag == -2) { const char* e = getenv("IBL_GEMM_STAGGER"); stag = e ? atoi(e) : 0; }
+        e2.stagger = stag;
+    }
     void* tok;
     ibl_prof_begin(IBL_PROF_GEMM, 2.0 * (double)M * (double)N * (double)(epi.algo_k < 0 ? 0 : (epi.algo_k ? epi.algo_k : K)), s, &tok);
-    hipLaunchKernelGGL((ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS, PIPE>), dim3(grid), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((ibl_gemm_f16_tn<EPI, MI, WM, WN, BK, OCC, NS, PIPE>), dim3(grid), dim3(WM * WN * 64), lds, s, A, lda, W, ldw, M, N, K, e2);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     return IBL_OK;

@@ -467,16 +467,23 @@ class LocaliseEngine:
             close_timings()
             return results
         # ---- stage B in one library call (ibl_register_evaluate_batch, csrc/localise.hip): what the staged sequence below computes, bit
-        # for bit (tests/test_gpu_engine.py), without Python or torch between the launches.  The staged form remains for per-stage
-        # timings, for reuse_features = False and for sharded clouds (whose stages are separated by collectives).
-        if self.fused_stage_b and timings is None and self.route is None and self.reuse_features:
+        # for bit (tests/test_gpu_engine.py), without Python or torch between the launches.  The staged form remains for
+        # reuse_features = False and for sharded clouds (whose stages are separated by collectives).
+        if self.fused_stage_b and self.route is None and self.reuse_features:
             if not any(len(a) for a in assns):
+                close_timings()
                 return results
             thr = eval_threshold if eval_threshold is not None else mem.eval_threshold
             r = register_evaluate_batch(ctx, det, q_per_frame, assns, mem.clouds, mem.features(fpfh_voxel_size, fpfh_local_dist_factor), mem.grid,
                                         fpfh_voxel_size, fpfh_global_dist_factor, fpfh_local_dist_factor, outlier_radius, outlier_nb_points, thr,
                                         seed=seed, job_id_base=job_id_base, ransac_max_iter=ransac_max_iter, fixed_budget=ransac_fixed_budget)
-            return self._assemble(results, assns, row0, r["clean_off"], r, r["T_global"], r["full_rmse"], r["full_fitness"])
+            if timings is not None:
+                timings["reuse"] = r["reuse"].tolist()
+            tick("stage_b")              # (the split of stage B into its stages: the library's in-process stage timer, prof.stage_rooflines)
+            self._assemble(results, assns, row0, r["clean_off"], r, r["T_global"], r["full_rmse"], r["full_fitness"])
+            tick("select")
+            close_timings()
+            return results
         # ---- clean the detected clouds (:992-998) ---------------------------------------------------
         keep = radius_outlier_batch(ctx, det, outlier_radius, outlier_nb_points)
         keepb = keep.bool()
