@@ -77,13 +77,16 @@ for tag, path in (("vit", f"{pmc}/vit_mfma_counter_collection_ibl_kernels.csv"),
         wave = max(s.get("SQ_WAVE_CYCLES", 0.0), 1.0)
         if cyc <= 0:
             continue
+        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count QUAD-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (MI355X_MICROARCH.md, PMC units)
         e = {"launches": len(v.get("GRBM_GUI_ACTIVE", [])), "wait_any_share": s.get("SQ_WAIT_ANY", 0.0) / wave,
              "wait_inst_share": s.get("SQ_WAIT_INST_ANY", 0.0) / wave, "active_inst_share": s.get("SQ_ACTIVE_INST_ANY", 0.0) / wave,
-             "mean_waves_per_simd": wave / (cyc * 1024.0)}
+             "mean_waves_per_simd": 4.0 * wave / (cyc * 1024.0)}
         if "SQ_VALU_MFMA_BUSY_CYCLES" in s:
             e["mfma_util"] = s["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
         if "SQ_ACTIVE_INST_VALU" in s:
-            e["valu_util"] = s["SQ_ACTIVE_INST_VALU"] / (cyc * 1024.0)
+            e["valu_util"] = 4.0 * s["SQ_ACTIVE_INST_VALU"] / (cyc * 1024.0)
+        if "SQ_INSTS_VALU" in s:
+            e["valu_insts_per_launch"] = s["SQ_INSTS_VALU"] / max(1, e["launches"])
         split[k] = e
 json.dump(split, open(f"{out}/wave_split.json", "w"), indent=1, sort_keys=True)
 print(open(f"{out}/hbm_per_kernel.txt").read())
