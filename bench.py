@@ -520,6 +520,9 @@ def main():
             "feature_reuse_last_step": timings.get("reuse"),
         }
         print(json.dumps(out))
+    if eng.exchange is not None and eng.exchange.comm is not None:       # the library's RCCL communicator: released by every rank, before
+        torch.cuda.synchronize()                                            # torch's process group goes
+        eng.exchange.comm.close()
     if world_size > 1:
         dist.destroy_process_group()
 

@@ -84,10 +84,10 @@ struct GlobalAcc {
 };
 struct TileAcc {
     const float4* pts;       // LDS
-    const int* ordl;         // LDS
+    const int* ordl;         // LDS, or null: the original index rides in the w component of the staged point (packed tiles)
     int key_base, key_span;  // the original indices of the tile's segment lie in [key_base, key_base + key_span)
     __device__ __forceinline__ float4 pt(int h) const { return pts[h]; }
-    __device__ __forceinline__ int ord(int h) const { return ordl[h]; }
+    __device__ __forceinline__ int ord(int h) const { return ordl ? ordl[h] : __float_as_int(pts[h].w); }
 };
 // key range of the handles a consumer sorts by original index: known up front for a tile (its segment), found by a reduction otherwise
 __device__ __forceinline__ bool key_range_hint(const GlobalAcc&, int*, unsigned*) { return false; }
@@ -96,15 +96,20 @@ __device__ __forceinline__ bool key_range_hint(const TileAcc& a, int* kmin, unsi
 // LDS-staged neighbourhood of one tile (a cube of ts^3 cells): every point of the cube of `rho` cells around the tile, copied once
 // per workgroup and searched by all the tile's queries
 #define KT_ROWS 144          // candidate rows (z, y) of the staging cube: (ts + 2 rho)^2 <= 144
-template <int KT_CAP>        // staged candidates
+// PACK: the consumer never reads a staged point's intensity (normals, SPFH: geometry only), so the point's original index is staged in
+// its w component and the separate index array (4 B per candidate: 10 KB of the tile) goes -- with it and six waves per workgroup the
+// 100-neighbour search keeps three waves per SIMD resident instead of two.
+template <int KT_CAP, bool PACK = false>        // staged candidates
 struct TileLds {
     static constexpr int CAP = KT_CAP;
+    static constexpr bool PACKED = PACK;
     float4 pts[KT_CAP];
-    int ord[KT_CAP];
+    int ord[PACK ? 1 : KT_CAP];
     int row_b[KT_ROWS];
     int row_off[KT_ROWS + 1];
     int q_b[16];
     int q_off[17];
+    __device__ __forceinline__ int ord_of(int t) const { return PACK ? __float_as_int(pts[t].w) : ord[t]; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -544,6 +549,9 @@ struct NormalPendingT {
 typedef NormalPendingT<NP_SLOTS> NormalPending;
 struct NoPending { int n; };
 
+// the nine moment sums of a normal's neighbours (ascending original index) -> covariance -> smallest eigenvector
+__device__ __forceinline__ void normal_from_moments(double* c, int k, int qi, float4* __restrict__ normals);
+
 template <class Acc, class H>
 __device__ __forceinline__ void normal_solve(const Acc& acc, const H* __restrict__ hnd, int k, int qi, float4* __restrict__ normals) {
     double c[9];
@@ -555,6 +563,10 @@ __device__ __forceinline__ void normal_solve(const Acc& acc, const H* __restrict
         c[0] += x; c[1] += y; c[2] += z;
         c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
     }
+    normal_from_moments(c, k, qi, normals);
+}
+
+__device__ __forceinline__ void normal_from_moments(double* c, int k, int qi, float4* __restrict__ normals) {
     double n[3];
     if (k >= 3) {
 #pragma unroll
@@ -748,8 +760,11 @@ struct ListNormalConsumer {
     // same histogram, so finish() need not find them again (its 64-bin histogram and rank loops were 4 300 of a query's 24 000 clocks)
     static constexpr bool WANTS_INNER = true;
     bool flagged = false;    // accept_in() was used: bit 31 of the stored d2 marks an inner neighbour
-    typedef NormalPendingT<NP_SLOTS_FUSED> PT;
-    float4* normals;         // out, original order
+    // Round 3: the consumer no longer solves the normal.  It records WHICH entries of the query's neighbour list are the normal's
+    // neighbours as a 128-bit mask over the list slots (the list is in ascending original index: the order of the covariance sums);
+    // ibl_normals_from_mask_kernel then solves every point of the batch with one lane per point.  In this kernel the solve ran on 8 of
+    // 64 lanes, every eighth query, behind ~250 VGPRs of fp64 code (the tile kernel spilled), and kept 2.3 KB of LDS per workgroup.
+    unsigned* nrm_mask;      // out [N][4]
     Acc acc;
     int* nbr_idx;            // [N][K]
     float* nbr_d2;           // [N][K]
@@ -759,7 +774,6 @@ struct ListNormalConsumer {
     int kn;                  // normal neighbours (<= NP_MAXK)
     int qi;
     WaveLds* L;
-    PT* P;
     int ncount;
     __device__ void begin(int) { ncount = 0; }
     __device__ void accept(bool sel, int j, const float4&, float d2) {
@@ -785,37 +799,23 @@ struct ListNormalConsumer {
     }
     __device__ void finish_flagged(int k) {
         const int lane = threadIdx.x & 63;
-        const unsigned long long lt_mask = (1ull << lane) - 1ull;
         sort_selected_by_index<true>(L, acc, k);                  // b_j: handles, b_bits: d2 bits | inner flag, ascending original index
-        const bool immediate = P == nullptr;
-        const int slot = immediate ? 0 : P->n;
-        int kq = 0;
-        for (int t0 = 0; t0 < k; t0 += 64) {
-            const int t = t0 + lane;
+        unsigned long long mm[2] = {0ull, 0ull};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int t = 64 * c + lane;
             const bool v = t < k;
             const unsigned bits = v ? L->b_bits[t] : 0u;
-            const int h = v ? L->b_j[t] : 0;
             if (v) {
-                nbr_idx[(int64_t)qi * K + t] = acc.ord(h);
+                nbr_idx[(int64_t)qi * K + t] = acc.ord(L->b_j[t]);
                 nbr_d2[(int64_t)qi * K + t] = __uint_as_float(bits & 0x7FFFFFFFu);
             }
-            const bool member = v && (bits >> 31) != 0u;
-            const unsigned long long mm = __ballot(member);
-            if (member) {
-                const int pos = kq + __popcll(mm & lt_mask);
-                if (immediate) L->b_idx[pos] = h;
-                else P->h[slot][pos] = (unsigned short)h;
-            }
-            kq += __popcll(mm);
+            mm[c] = __ballot(v && (bits >> 31) != 0u);
         }
-        if (lane == 0) nbr_cnt[qi] = k;
-        if (immediate) {
-            wave_lds_sync();
-            if (lane == 0) normal_solve(acc, L->b_idx, kq, qi, normals);
-        } else {
-            if (lane == 0) { P->qi[slot] = qi; P->k[slot] = kq; P->n = slot + 1; }
-            if (slot + 1 == PT::SLOTS) normal_flush(P, acc, normals);
-            else wave_lds_sync();
+        if (lane == 0) {
+            nbr_cnt[qi] = k;
+            *reinterpret_cast<uint4*>(nrm_mask + 4 * (int64_t)qi) =
+                make_uint4((unsigned)mm[0], (unsigned)(mm[0] >> 32), (unsigned)mm[1], (unsigned)(mm[1] >> 32));
         }
     }
     __device__ void finish(int k) {
@@ -873,9 +873,7 @@ struct ListNormalConsumer {
             }
             wave_lds_sync();
         }
-        const bool immediate = P == nullptr;
-        const int slot = immediate ? 0 : P->n;
-        int kq = 0;
+        unsigned long long mmk[2] = {0ull, 0ull};
         for (int t0 = 0; t0 < k; t0 += 64) {
             const int t = t0 + lane;
             const float d2 = t < k ? __uint_as_float(L->b_bits[t]) : INFINITY;
@@ -893,23 +891,12 @@ struct ListNormalConsumer {
                     member = rank < need;
                 }
             }
-            const unsigned long long mm = __ballot(member);
-            if (member) {
-                const int pos = kq + __popcll(mm & lt_mask);
-                if (immediate) L->b_idx[pos] = L->b_j[t];
-                else P->h[slot][pos] = (unsigned short)L->b_j[t];
-            }
-            kq += __popcll(mm);
+            mmk[t0 >> 6] = __ballot(member);
         }
         KNN_CLK(15);
-        if (immediate) {
-            wave_lds_sync();
-            if (lane == 0) normal_solve(acc, L->b_idx, kq, qi, normals);
-        } else {
-            if (lane == 0) { P->qi[slot] = qi; P->k[slot] = kq; P->n = slot + 1; }
-            if (slot + 1 == PT::SLOTS) normal_flush(P, acc, normals);
-            else wave_lds_sync();
-        }
+        if (lane == 0)
+            *reinterpret_cast<uint4*>(nrm_mask + 4 * (int64_t)qi) =
+                make_uint4((unsigned)mmk[0], (unsigned)(mmk[0] >> 32), (unsigned)mmk[1], (unsigned)(mmk[1] >> 32));
     }
 };
 
@@ -1120,7 +1107,7 @@ __device__ int tile_select_guess(const TL& T, int total, const float4 q, float c
                     if (pk) {
                         const int pos = c30 + __popcll(mp & lt_mask);
                         L->rank_pre[pos] = (int)eb[u];
-                        L->scratch[pos] = T.ord[et[u]];
+                        L->scratch[pos] = T.ord_of(et[u]);
                     }
                     c30 += __popcll(mp);
                 }
@@ -1130,7 +1117,7 @@ __device__ int tile_select_guess(const TL& T, int total, const float4 q, float c
                     if (ebin[u] < b30) inner[u] = true;
                     else if (ebin[u] > b30) inner[u] = false;
                     else {
-                        const int mi = T.ord[et[u]];
+                        const int mi = T.ord_of(et[u]);
                         int rank = 0;
                         for (int w = 0; w < pop30; ++w) {
                             const unsigned ub = (unsigned)L->rank_pre[w];
@@ -1160,7 +1147,7 @@ __device__ int tile_select_guess(const TL& T, int total, const float4 q, float c
         if (park) {
             const int pos = bcount + __popcll(m & lt_mask);
             L->b_bits[pos] = eb[u];
-            L->b_idx[pos] = T.ord[et[u]];
+            L->b_idx[pos] = T.ord_of(et[u]);
             bool fl = false;
             if constexpr (Consumer::WANTS_INNER) fl = use_flags && inner[u];
             L->b_j[pos] = et[u] | (fl ? 0x40000000 : 0);        // (bit 30: inner flag of a parked entry)
@@ -1289,7 +1276,7 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
             if (park) {
                 const int pos = bcount + __popcll(m & lt_mask);
                 L->b_bits[pos] = bits;
-                L->b_idx[pos] = T.ord[t];
+                L->b_idx[pos] = T.ord_of(t);
                 L->b_j[pos] = t;
             }
             bcount += __popcll(m);
@@ -1309,7 +1296,7 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
             if (park) {
                 const int pos = bcount + __popcll(m & lt_mask);
                 L->b_bits[pos] = __float_as_uint(d2);
-                L->b_idx[pos] = T.ord[t];
+                L->b_idx[pos] = T.ord_of(t);
                 L->b_j[pos] = t;
             }
             bcount += __popcll(m);
@@ -1346,7 +1333,7 @@ __device__ bool tile_select(const TL& T, int total, const float4 q, float cover2
 // (pi rho^2)); the reach grows from 2 until it does, the cube fills the LDS budget or covers the whole radius.
 struct NeedPop { float v[8]; int rho_start; int guess; };       // guess: tile_select_guess on (0: IBL_KNN_NOGUESS=1, the two-pass selection only)
 
-template <int TS, class TL, class Factory>
+template <int TS, int NW, class TL, class Factory>
 __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int max_nn, const NeedPop& need_pop, int* __restrict__ fb_list,
                                int* __restrict__ fb_count, const Factory& fac, int q_lo, int q_hi, TL& T, WaveLds* wl,
                                typename Factory::Pending* pend) {
@@ -1433,15 +1420,17 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     KNN_CLK(1);
     if (staged) {
         const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-        for (int t = tid; t < total; t += 256) {
+        for (int t = tid; t < total; t += NW * 64) {
             int a = 0, b = nrows;                      // the row r with row_off[r] <= t < row_off[r + 1]
             while (b - a > 1) {
                 const int mid = (a + b) >> 1;
                 if (T.row_off[mid] <= t) a = mid; else b = mid;
             }
             const int j = T.row_b[a] + (t - T.row_off[a]);
-            T.pts[t] = g.sorted_pts[j];
-            T.ord[t] = g.order[j];
+            float4 sp = g.sorted_pts[j];
+            if (TL::PACKED) sp.w = __int_as_float(g.order[j]);
+            else T.ord[t] = g.order[j];
+            T.pts[t] = sp;
         }
     }
     __syncthreads();
@@ -1458,7 +1447,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     wave_lds_sync();
     // original-index range of the tile's segment (points are sorted by (segment, cell): a segment's sorted positions are its indices)
     const int key_base = g.cell_start[sg.cell_base];
-    const TileAcc tacc{T.pts, T.ord, key_base, g.cell_start[sg.cell_base + sg.nx * sg.ny * sg.nz] - key_base};
+    const TileAcc tacc{T.pts, TL::PACKED ? nullptr : T.ord, key_base, g.cell_start[sg.cell_base + sg.nx * sg.ny * sg.nz] - key_base};
     // threshold-bin guess carried from query to query of this wave.  To start (a tile holds ~9 queries, so the four waves' first
     // queries are 4 of 9): a pilot -- the whole workgroup histograms the staged candidates around the tile's middle query (five steps
     // of 256 threads) and the bin that holds its max_nn-th neighbour, + the margin, seeds every wave.  A guess that is too small or
@@ -1468,14 +1457,14 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
     if (staged && nq > 4) {
         int* ph = wl[0].hist;                          // idle until the first query
         __shared__ int pilot_bin;
-        for (int t = tid; t < KNN_BINS; t += 256) ph[t] = 0;
+        for (int t = tid; t < KNN_BINS; t += NW * 64) ph[t] = 0;
         __syncthreads();
         int pr = 0;
         const int pk = nq >> 1;
         while (pk >= T.q_off[pr + 1]) ++pr;
         const float4 pq = g.sorted_pts[T.q_b[pr] + (pk - T.q_off[pr])];
         const float bscale = (float)KNN_BINS / r2;
-        for (int t = tid; t < total; t += 256) {
+        for (int t = tid; t < total; t += NW * 64) {
             const float4 p = T.pts[t];
             const float d2 = dist2f(pq.x, pq.y, pq.z, p.x, p.y, p.z);
             if (d2 < r2) atomicAdd(&ph[min((int)(d2 * bscale), KNN_BINS - 1)], 1);
@@ -1513,7 +1502,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
 #endif
     int run_r = 0;
     const int sny = y1 - y0 + 1;
-    for (int qk = wave; qk < nq; qk += 4) {
+    for (int qk = wave; qk < nq; qk += NW) {
         while (qk >= T.q_off[run_r + 1]) ++run_r;
         const int jq = T.q_b[run_r] + (qk - T.q_off[run_r]);
         // a query is a point of the tile, and the tile lies inside its staged cube: the point and its original index come from LDS (the two
@@ -1523,7 +1512,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
         if (staged) {
             const int sr = (cz0 + run_r / qny - z0) * sny + (cy0 + run_r % qny - y0);
             const int ts_ = T.row_off[sr] + (jq - T.row_b[sr]);
-            qi = T.ord[ts_];
+            qi = T.ord_of(ts_);
             q = T.pts[ts_];
         } else {
             qi = g.order[jq];
@@ -1553,6 +1542,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
 }
 
 struct NormalFactory {
+    static constexpr bool WIDE = false;      // (its pending normals are solved by a 4-wave block flush)
     typedef NormalPending Pending;
     float4* normals;
     template <class Acc> __device__ NormalConsumer<Acc> make(int qi, const float4&, WaveLds* L, const Acc& acc, Pending* P = nullptr) const {
@@ -1564,6 +1554,7 @@ struct NormalFactory {
     template <class Acc> __device__ void flush_block(Pending* pend, const Acc& acc) const { normal_flush_block(pend, acc, normals); }
 };
 struct SpfhFactory {
+    static constexpr bool WIDE = true;       // six waves per workgroup + packed tile for the 100-neighbour search (geometry only)
     typedef NoPending Pending;
     const float4* normals; unsigned char* spfh_cnt; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K;
     template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
@@ -1576,18 +1567,20 @@ struct SpfhFactory {
     }
 };
 struct ListNormalFactory {
-    typedef NormalPendingT<NP_SLOTS_FUSED> Pending;
-    float4* normals; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K; float rn2; int kn;
-    template <class Acc> __device__ void flush(Pending* P, const Acc& acc) const { normal_flush(P, acc, normals); }
-    template <class Acc> __device__ void flush_block(Pending* pend, const Acc& acc) const { normal_flush_block(pend, acc, normals); }
-    template <class Acc> __device__ ListNormalConsumer<Acc> make(int qi, const float4&, WaveLds* L, const Acc& acc, Pending* P = nullptr) const {
+    static constexpr bool WIDE = true;
+    typedef NoPending Pending;
+    unsigned* nrm_mask; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K; float rn2; int kn;
+    template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
+    template <class Acc> __device__ void flush_block(Pending*, const Acc&) const {}
+    template <class Acc> __device__ ListNormalConsumer<Acc> make(int qi, const float4&, WaveLds* L, const Acc& acc, Pending* = nullptr) const {
         ListNormalConsumer<Acc> c;
-        c.normals = normals; c.acc = acc; c.nbr_idx = nbr_idx; c.nbr_d2 = nbr_d2; c.nbr_cnt = nbr_cnt; c.K = K; c.rn2 = rn2; c.kn = kn;
-        c.qi = qi; c.L = L; c.P = P; c.ncount = 0;
+        c.nrm_mask = nrm_mask; c.acc = acc; c.nbr_idx = nbr_idx; c.nbr_d2 = nbr_d2; c.nbr_cnt = nbr_cnt; c.K = K; c.rn2 = rn2; c.kn = kn;
+        c.qi = qi; c.L = L; c.ncount = 0;
         return c;
     }
 };
 struct GradFactory {
+    static constexpr bool WIDE = false;      // (reads the staged intensity: no room for the index in w)
     typedef NoPending Pending;
     const float4* normals; float4* grad;
     template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
@@ -1599,14 +1592,14 @@ struct GradFactory {
     }
 };
 
-// tiles: one workgroup each
-template <int TS, int CAP, class Factory>
-__global__ __launch_bounds__(256) void ibl_knn_tile_kernel(BatchGrid g, float radius, float r2, int max_nn, NeedPop need_pop, Factory fac,
-                                                           int q_lo, int q_hi, int* __restrict__ fb_list, int* __restrict__ fb_count) {
-    __shared__ TileLds<CAP> T;
-    __shared__ WaveLds wl[4];
-    __shared__ typename Factory::Pending pend[4];
-    tile_knn_block<TS>(g, radius, r2, max_nn, need_pop, fb_list, fb_count, fac, q_lo, q_hi, T, wl, pend);
+// tiles: one workgroup each.  NW waves per workgroup; PACK: original indices in the staged points' w (see TileLds)
+template <int TS, int CAP, class Factory, int NW = 4, bool PACK = false>
+__global__ __launch_bounds__(NW * 64) void ibl_knn_tile_kernel(BatchGrid g, float radius, float r2, int max_nn, NeedPop need_pop, Factory fac,
+                                                              int q_lo, int q_hi, int* __restrict__ fb_list, int* __restrict__ fb_count) {
+    __shared__ TileLds<CAP, PACK> T;
+    __shared__ WaveLds wl[NW];
+    __shared__ typename Factory::Pending pend[NW];
+    tile_knn_block<TS, NW>(g, radius, r2, max_nn, need_pop, fb_list, fb_count, fac, q_lo, q_hi, T, wl, pend);
 }
 
 // the queries the tile kernel could not answer from its staged cubes: one wavefront each, walking the grid (sorted positions in list)
@@ -1774,6 +1767,14 @@ static int launch_knn(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, c
         const NeedPop np = need_pop_table(max_nn, g.ts);
         // LDS budget of the staged cube: 20 B per candidate.  The 100-neighbour search (tiles of 2^3 cells) stages up to 2 560 points
         // (77 KiB per workgroup with the four waves' selection scratch: two workgroups per CU), the 30-neighbour ones 1 024
+        // Measured and rejected (round 3): six waves per workgroup on a packed tile (original index in the staged point's w: 2 528 candidates
+        // x 16 B + six waves' scratch = 81.7 KB, 129 VGPRs: two workgroups = TWELVE waves per CU instead of eight) ran the 100-neighbour
+        // search in 7.13 ms against 5.27 ms -- more resident waves do not help this kernel, the per-tile set-up and barriers are then
+        // shared by 3.5 instead of 5.3 queries per wave.  -DIBL_KNN_WIDE builds that form.
+#ifdef IBL_KNN_WIDE
+        if (g.ts == 2 && Factory::WIDE) hipLaunchKernelGGL((ibl_knn_tile_kernel<2, 2528, Factory, 6, true>), dim3(g.n_tiles), dim3(384), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
+        else
+#endif
         if (g.ts == 2) hipLaunchKernelGGL((ibl_knn_tile_kernel<2, 2560, Factory>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
         else if (g.ts == 4) hipLaunchKernelGGL((ibl_knn_tile_kernel<4, 1024, Factory>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
         else return ibl_set_error(IBL_ERR_INTERNAL, "k-NN tiles of %d^3 cells are not built", g.ts);
@@ -1833,6 +1834,35 @@ int ibl_launch_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, con
     return IBL_OK;
 }
 
+// Normals of every point from its neighbour list and the 128-bit mask of the list slots that are the normal's own neighbours (written by
+// ListNormalConsumer): one lane per point, the moment sums in list order = ascending original index, exactly the arithmetic of
+// normal_solve -- a point's normal does not depend on which kernel found its neighbours.
+__global__ __launch_bounds__(256) void ibl_normals_from_mask_kernel(const float4* __restrict__ pts, const int* __restrict__ nbr_idx, int K,
+                                                                    const unsigned* __restrict__ nrm_mask, int n, float4* __restrict__ normals) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= n) return;
+    const uint4 m4 = *reinterpret_cast<const uint4*>(nrm_mask + 4 * (int64_t)qi);
+    const unsigned w[4] = {m4.x, m4.y, m4.z, m4.w};
+    double c[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) c[t] = 0.0;
+    int k = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unsigned bits = w[u];
+        while (bits) {
+            const int t = 32 * u + __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            const float4 p = pts[nbr_idx[(int64_t)qi * K + t]];
+            const double x = p.x, y = p.y, z = p.z;
+            c[0] += x; c[1] += y; c[2] += z;
+            c[3] += x * x; c[4] += x * y; c[5] += x * z; c[6] += y * y; c[7] += y * z; c[8] += z * z;
+            ++k;
+        }
+    }
+    normal_from_moments(c, k, qi, normals);
+}
+
 // SPFH histograms from stored neighbour lists (after the fused search above has written lists and normals): wave per point
 __global__ __launch_bounds__(256) void ibl_spfh_lists_kernel(const float4* __restrict__ pts, const float4* __restrict__ normals,
                                                              const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt, int K, int n,
@@ -1864,19 +1894,24 @@ __global__ __launch_bounds__(256) void ibl_spfh_lists_kernel(const float4* __res
 bool ibl_normals_fpfh_fusable(double radius_normal, int max_nn_normal, double radius_feature, int max_nn_feature) {
     const char* e = getenv("IBL_FEAT_UNFUSED");          // diagnostics: 1 = the two separate searches (read per call: the tests compare both)
     const bool off = e && atoi(e);
-    return !off && radius_normal <= radius_feature && max_nn_normal <= max_nn_feature && max_nn_normal <= NP_MAXK && max_nn_feature <= 256;
+    return !off && radius_normal <= radius_feature && max_nn_normal <= max_nn_feature && max_nn_normal <= NP_MAXK && max_nn_feature <= 128;   // (128-slot mask)
 }
 int ibl_launch_normals_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, const int* seg_off, int n, double radius_normal,
                             int max_nn_normal, double radius_feature, int max_nn_feature, float4* normals, unsigned char* spfh, int* nbr_idx,
                             float* nbr_d2, int* nbr_cnt, float* fpfh, int matching_order, int* status, hipStream_t s) {
     if (n <= 0) return IBL_OK;
+    ArenaMark mk(ctx);                  // (the mask is read by the kernel launched below, on the same stream)
+    unsigned* nrm_mask;
+    IBL_ARENA(nrm_mask, unsigned, 4 * (int64_t)n + 64);
     void* tok;
     ibl_prof_begin(IBL_PROF_SPFH, 156.0 * (double)n, s, &tok);
     const int st = launch_knn(ctx, g, pts, seg_off, n, 0, n, radius_feature, max_nn_feature,
-                              ListNormalFactory{normals, nbr_idx, nbr_d2, nbr_cnt, max_nn_feature, (float)(radius_normal * radius_normal), max_nn_normal},
+                              ListNormalFactory{nrm_mask, nbr_idx, nbr_d2, nbr_cnt, max_nn_feature, (float)(radius_normal * radius_normal), max_nn_normal},
                               status, s);
     ibl_prof_end(tok, s);
     if (st) return st;
+    hipLaunchKernelGGL(ibl_normals_from_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, nbr_idx, max_nn_feature, nrm_mask, n, normals);
+    IBL_LAUNCH_CHECK();
     hipLaunchKernelGGL(ibl_spfh_lists_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pts, normals, nbr_idx, nbr_cnt, max_nn_feature, n, spfh);
     IBL_LAUNCH_CHECK();
     if (fpfh) {
