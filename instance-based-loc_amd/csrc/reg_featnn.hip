@@ -3,8 +3,9 @@
 // The search (utils/fpfh_register.py:110-119 -> Open3D's feature matching: for every point the nearest feature of the other
 // cloud) is a dense distance matrix: 5 000 x 5 000 rows per instance pair, ~600 pairs and both directions per bench step.  The
 // matrix cores do the bulk and the exact arithmetic is kept for the few candidates that can matter.  Every feature row is stored
-// once more as 48 fp16 "search operands" (ibl_fpfh_half_kernel):
-//   x'  = [ x_0 .. x_32 | 8  8 | nh  nl | cu | 0 ... ]      nh + nl = |x|^2 / 8 (fp16 hi + lo),  cu = C |x|^2 rounded up
+// once more as 48 fp16 "search operands" (ibl_fpfh_half_kernel) of the CENTRED row x = row - FM_MU (a constant vector: distances are
+// unchanged, the norms -- and with them the error band below -- shrink to ~0.35 of the raw rows'; reg_api.hip):
+//   x'  = [ x_0 .. x_32 | 8  8 | nh  nl | cu | 0 ... ]      nh + nl = |x|^2 / 8 (fp16 hi + lo),  cu = C |x|^2 + A rounded up
 // and a query row is turned in registers into
 //   q'' = [ -2 q_0 .. -2 q_32 | sh  sl | 8  8 | +-1 | 0 ... ]   sh + sl = (1 +- C) |q|^2 / 8
 // so that ONE MFMA chain (three v_mfma_f32_32x32x16_f16 over the 48 terms) yields the whole bound
@@ -17,7 +18,11 @@
 //   accumulate 38 exact fp16 products summed in fp32 by the MFMAs (largest partial sum ~N):                    <= 0.5e-5 N
 //   norms      fp32 fmaf chains, stored as fp16 hi + lo pairs (2^-22 relative):                                <= 0.3e-5 N
 //   chain      the exact chain's own rounding (34 roundings of values <= d2 <= 2 N):                           <= 0.4e-5 N
-// total <= 9.9e-4 N; E = FM_C N with FM_C = 1.0e-3 (the C|t|^2 slot is rounded UP to fp16, the query's factor is applied in fp32).
+//   centring   x = fl(row - mu) carries 2^-24 |x| per component into d2_approx against the chain on the raw rows:  <= 0.02e-5 N
+//   absolute   a centred component (or norm term) in fp16's subnormal range is rounded to 2^-25 absolute instead of 2^-11
+//              relative: <= 2 * 33 * 2 * 200 * 2^-25 = 8e-4 for the products, 8 * 2 * 2^-25 for the norm terms:    <= A = 4e-3
+// total <= 9.9e-4 N + A; E = FM_C N + A with FM_C = 1.0e-3 (the C|t|^2 + A slot is rounded UP to fp16, the query's factor is applied
+// in fp32).
 //   pass 1   up(q) = min_t (d2_approx + E)                    -- an upper bound of the exact minimum
 //   pass 2   every t with d2_approx - E <= up(q) is a candidate -- the exact minimiser (and every exact tie) is among them
 //   exact    the fp32 fmaf chain of the VALU search for each candidate, folded with a 64-bit atomic min on
@@ -44,6 +49,7 @@ typedef __attribute__((ext_vector_type(16))) float fm_f32x16;
 #define FM_C 1.0e-3f             // E = FM_C (|q|^2 + |t|^2)
 #define FM_NS 8.0f               // norms are stored divided by 8 (|x|^2 reaches 1.2e5, fp16 ends at 65 504) against a constant 8
 #define FM_NQ 2                  // 32-query tiles per wave (they share every database fragment read)
+#define FM_P1_STRIDE 2           // pass 1 visits one database chunk in FM_P1_STRIDE (ibl_feat_search_mfma)
 #define FM_QUEUE 256             // per-wave candidate queue, flushed when fewer than 64 slots (one append step) are left
 
 struct FmCand { int pair, qi, t, pad; };
@@ -63,9 +69,9 @@ __device__ __forceinline__ void fm_split_norm(float v, _Float16* h, _Float16* l)
 // (fpfh_split: 48 fp16 per row, laid out as in the file header).  Database chunks of 32 rows are copied to LDS (16-byte pieces,
 // fetched into registers one chunk ahead); every wave holds its 32 queries as the B operand in registers.
 template <int PASS, bool INDEXED>
-__global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __restrict__ pairs, FeatSources src, float* __restrict__ up,
+__global__ __launch_bounds__(256, 2) void ibl_feat_mfma_kernel(const FeatPair* __restrict__ pairs, FeatSources src, float* __restrict__ up,
                                                             FmCand* __restrict__ cand, unsigned long long* __restrict__ n_cand, int cand_cap,
-                                                            const int* __restrict__ need_pos, const int* __restrict__ need_list, int out0) {
+                                                            const int* __restrict__ need_pos, const int* __restrict__ need_list, int out0, int cstride) {
     const FeatPair P = pairs[blockIdx.y];
     int n_q = P.qcnt, l0 = 0;
     if (INDEXED) { l0 = need_pos[P.out - out0]; n_q = need_pos[P.out - out0 + P.qcnt] - l0; }
@@ -146,13 +152,14 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
         __builtin_amdgcn_wave_barrier();
         qcount = 0;
     };
+    // pass 1 visits every cstride-th chunk only (file header: any non-empty subset of the database gives a valid upper bound)
     fetch(0);
     stash(tiles[0]);
     __syncthreads();
-    for (int c = 0; c < n_chunks; ++c) {
-        FmTile& T = tiles[c & 1];
-        const bool more = c + 1 < n_chunks;
-        if (more) fetch((c + 1) * FM_DT);
+    for (int c = 0, it = 0; c < n_chunks; c += cstride, ++it) {
+        FmTile& T = tiles[it & 1];
+        const bool more = c + cstride < n_chunks;
+        if (more) fetch((c + cstride) * FM_DT);
         // all fragment reads of the chunk first: the MFMAs of its first 32 rows run while the later reads return
         fm_h16x8 ah[FM_SUB][3];
 #pragma unroll
@@ -177,30 +184,39 @@ __global__ __launch_bounds__(256) void ibl_feat_mfma_kernel(const FeatPair* __re
         // and query n of tile u
 #pragma unroll
         for (int u = 0; u < FM_NQ; ++u) {
-            float lowest = INFINITY;
+            // minima of the four groups of four accumulators (rows 8 g + 4 kg + 0..3), then of the tile
+            float gm[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lowest = fminf(lowest, acc[u][i]);
+            for (int g = 0; g < 4; ++g) gm[g] = fminf(fminf(acc[u][4 * g], acc[u][4 * g + 1]), fminf(acc[u][4 * g + 2], acc[u][4 * g + 3]));
+            const float lowest = fminf(fminf(gm[0], gm[1]), fminf(gm[2], gm[3]));
             if (PASS == 1) {
                 mup[u] = fminf(mup[u], lowest);
-            } else if (__ballot(lowest <= mup[u] && valid[u]) != 0ull) {
+            } else if (__builtin_amdgcn_ballot_w64(lowest <= mup[u] && valid[u]) != 0ull) {
                 // some query of this tile has a candidate in this chunk: append to the wave's LDS queue (ballot compaction, no
                 // atomics); the queue goes to the global list in batches -- one atomic per ~200 candidates instead of one each
-                // (two million same-address atomics per step took longer than the whole search)
+                // (two million same-address atomics per step took longer than the whole search).  The groups without a hit are
+                // skipped as a whole: a hit is rare (0.2 - 0.4 per tile and chunk), and sixteen ballots per tile that has one made
+                // pass 2 take twice the time of pass 1.
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = c * FM_DT + 32 * h + 8 * (i >> 2) + 4 * kg + (i & 3);
-                    const bool hit = valid[u] && acc[u][i] <= mup[u] && row < P.dcnt;
-                    const unsigned long long m = __ballot(hit);
-                    if (m) {
-                        if (hit) queue[wave][qcount + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(qi[u], row);
-                        qcount += __popcll(m);
-                        if (qcount > FM_QUEUE - 64) flush();
+                for (int g = 0; g < 4; ++g) {
+                    if (__builtin_amdgcn_ballot_w64(gm[g] <= mup[u] && valid[u]) == 0ull) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g + e;
+                        const int row = c * FM_DT + 32 * h + 8 * g + 4 * kg + e;
+                        const bool hit = valid[u] && acc[u][i] <= mup[u] && row < P.dcnt;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                        if (m) {
+                            if (hit) queue[wave][qcount + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(qi[u], row);
+                            qcount += __popcll(m);
+                            if (qcount > FM_QUEUE - 64) flush();
+                        }
                     }
                 }
             }
         }
         }
-        if (more) stash(tiles[(c + 1) & 1]);        // the other buffer: its readers passed the barrier that ended chunk c - 1
+        if (more) stash(tiles[(it + 1) & 1]);       // the other buffer: its readers passed the barrier that ended the chunk before this one
         __syncthreads();
     }
     if (PASS == 1) {
@@ -263,17 +279,20 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
     IBL_HIP_CHECK(hipMemsetAsync(n_cand, 0, sizeof(unsigned long long), s));
     IBL_HIP_CHECK(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * (size_t)out_count, s));
     const bool indexed = need_pos != nullptr;
+    // pass 1 on every FM_P1_STRIDE-th chunk of the database: 1 / stride of a pass for a bound that is the stride-th smallest distance or so
+    static int p1s = -1;
+    if (p1s < 0) { const char* e = getenv("IBL_FEAT_P1_STRIDE"); p1s = e ? std::max(1, atoi(e)) : FM_P1_STRIDE; }
     for (int p0 = 0; p0 < n_pairs; p0 += 32768) {
         const unsigned np = (unsigned)std::min(32768, n_pairs - p0);
         const dim3 grid((max_q + 128 * FM_NQ - 1) / (128 * FM_NQ), np);
         if (indexed) {
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, true>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0);
+            hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, true>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, p1s);
             IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, true>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0);
+            hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, true>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, 1);
         } else {
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, false>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0);
+            hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, false>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, p1s);
             IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, false>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0);
+            hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, false>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, 1);
         }
         IBL_LAUNCH_CHECK();
     }
