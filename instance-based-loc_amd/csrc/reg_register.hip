@@ -40,6 +40,8 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
 #endif
 // (32 lanes per point from iteration 11 on measured 100 us per launch: the grid of 32x the blocks, nearly all of finished jobs, costs
 // more to schedule than the shorter walk saves)
+#define ICP_ACT_Y 32      // block rows of the ICP kernels once they walk the active-job list (iterations >= ICP_GROUP_FROM >= 1)
+static_assert(ICP_GROUP_FROM >= 1, "the first active-job list is written by the update of iteration ICP_GROUP_FROM - 1");
 #define ICP_BPJ 8        // blocks per job in the ICP / evaluation reductions (each ends in a 29-value fp64 block reduction)
 #define ICP_NACC 29      // 21 (JTJ upper) + 6 (JTr) + count + err2  |  p2p: 3 + 3 + 9 + count + err2
 
@@ -402,6 +404,9 @@ __global__ __launch_bounds__(256) void ibl_mutual_kernel(const int* __restrict__
 // ------------------------------------------------------------------------------------------------
 #define RANSAC_MAX_ROUND 262144
 #define RANSAC_FIRST_ROUND 4096
+#ifndef RANSAC_WIDE_MIN_BLOCKS
+#define RANSAC_WIDE_MIN_BLOCKS 1024       // fewer 16 k-hypothesis blocks than this in a round: 4 k blocks instead (run_round)
+#endif
 #define RANSAC_TAIL_JOBS 8                 // with at most this many jobs left ...
 #define RANSAC_TAIL_ROUND (1 << 20)        // ... a round walks this many hypotheses per job
 
@@ -776,8 +781,17 @@ __global__ void ibl_icp_init_kernel(IcpState* __restrict__ st, int J, const Rans
 // close), after which the other rows are skipped unless their distance lower bound can still reach the best -- a row is
 // only skipped when the bound is strictly larger, so equal distances are always compared by index and the result does
 // not depend on the scan order.
-// `best` / `*d2out` carry the minimum so far in and out (-1 / r2 to start): a target side is searched piece by piece.
-__device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, int best,
+// `pos` / `*d2out` carry the minimum so far in and out (-1 / r2 to start): a target side is searched piece by piece.  The minimum is
+// carried as a POSITION in the cell-sorted arrays (the caller reads g.order[pos] once, at the end).
+// Inner loop (round 3): eight candidates per step, their loads issued together (one thread's walk is a chain of dependent latencies);
+// the comparisons are branch-free selects -- the branchy form (`if (d2 < bd) ... else if (d2 == bd) ...` per candidate) compiled to ~10
+// exec-mask / branch instructions per candidate, more than the arithmetic.  An exact tie with the running best (equal fp32 distances of
+// two different points: duplicate points, symmetric configurations) is only DETECTED there; the step is then redone from its saved
+// state with the sequential rule (lowest original index wins), so the result is the sequential scan's, bit for bit.  Candidates past
+// the end of a row are clamped to its last point: a repeat of a candidate changes neither the minimum nor a tie.
+// (Round 3 also measured: pruning the row cell by cell -- own cell first, the others by their x gap -- 30 % slower: more dependent
+// cell-table loads than points saved.)
+__device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, int pos,
                                          float* d2out) {
     int reach = (int)ceilf(radius * sg.inv);
     if (reach < 1) reach = 1;
@@ -788,19 +802,31 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
     auto scan_row = [&](int z, int y) {
         const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
         const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-        // eight candidates per step: their loads are issued together (one thread's walk is a chain of dependent latencies --
-        // the kernel is bound by it, not by throughput); the comparisons keep the sequential order.  (Round 3: pruning the row cell by
-        // cell -- own cell first, the others by their x gap -- measured 30 % slower: more dependent cell-table loads than points saved.)
         for (int jj = b; jj < e; jj += 8) {
+            int c[8];
             float4 p[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = g.sorted_pts[min(jj + u, e - 1)];
+            for (int u = 0; u < 8; ++u) { c[u] = min(jj + u, e - 1); p[u] = g.sorted_pts[c[u]]; }
+            const float bd0 = bd;
+            const int pos0 = pos;
+            unsigned long long tie = 0ull;          // (wave masks OR-ed on the scalar unit: a per-lane flag got packed bit by bit)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (jj + u >= e) break;
                 const float d2 = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
-                if (d2 < bd) { bd = d2; best = g.order[jj + u]; }
-                else if (d2 == bd && best >= 0) { const int o = g.order[jj + u]; if (o < best) best = o; }
+                const bool lt = d2 < bd;
+                tie |= __builtin_amdgcn_ballot_w64((d2 == bd) & (c[u] != pos));          // (pos < 0: a d2 equal to r2 -- the redo rejects it)
+                bd = lt ? d2 : bd;
+                pos = lt ? c[u] : pos;
+            }
+            if (tie != 0ull) {          // rare: the sequential rule from the saved state
+                bd = bd0;
+                pos = pos0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {          // (unrolled: a loop would index p[] dynamically and put it in scratch)
+                    const float d2 = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+                    if (d2 < bd) { bd = d2; pos = c[u]; }
+                    else if (d2 == bd && pos >= 0 && c[u] != pos) { if (g.order[c[u]] < g.order[pos]) pos = c[u]; }
+                }
             }
         }
     };
@@ -821,15 +847,15 @@ __device__ __forceinline__ int nn_within(const BatchGrid& g, const SegGrid& sg, 
         }
     }
     *d2out = bd;
-    return best;
+    return pos;
 }
 
 // The same search by a GROUP of LPQ lanes per query (tail iterations of the ICP, below): a lane takes four consecutive candidates of
 // every 4 * LPQ, so a row of n candidates costs n / (4 LPQ) dependent load rounds instead of n / 8, and the lanes of a group share
 // their best distance after every row for the pruning.  The group's result is the (d2, index) lexicographic minimum over its lanes:
-// the same neighbour as nn_within, whatever the order.
+// the same neighbour as nn_within, whatever the order.  A lane's minimum is a position here too.
 template <int LPQ>
-__device__ __forceinline__ int nn_within_group(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, int sub, int best,
+__device__ __forceinline__ int nn_within_group(const BatchGrid& g, const SegGrid& sg, float qx, float qy, float qz, float radius, int sub, int pos,
                                                float* d2out) {
     int reach = (int)ceilf(radius * sg.inv);
     if (reach < 1) reach = 1;
@@ -844,15 +870,30 @@ __device__ __forceinline__ int nn_within_group(const BatchGrid& g, const SegGrid
         const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
         const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
         for (int jj = b + 4 * sub; jj < e; jj += 4 * LPQ) {
+            int c[4];
             float4 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = g.sorted_pts[min(jj + u, e - 1)];
+            for (int u = 0; u < 4; ++u) { c[u] = min(jj + u, e - 1); p[u] = g.sorted_pts[c[u]]; }
+            const float bd0 = bd;
+            const int pos0 = pos;
+            unsigned long long tie = 0ull;          // (wave masks OR-ed on the scalar unit: a per-lane flag got packed bit by bit)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (jj + u >= e) break;
                 const float d2 = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
-                if (d2 < bd) { bd = d2; best = g.order[jj + u]; }
-                else if (d2 == bd && best >= 0) { const int o = g.order[jj + u]; if (o < best) best = o; }
+                const bool lt = d2 < bd;
+                tie |= __builtin_amdgcn_ballot_w64((d2 == bd) & (c[u] != pos));          // (pos < 0: a d2 equal to r2 -- the redo rejects it)
+                bd = lt ? d2 : bd;
+                pos = lt ? c[u] : pos;
+            }
+            if (tie != 0ull) {
+                bd = bd0;
+                pos = pos0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {          // (unrolled: a loop would index p[] dynamically and put it in scratch)
+                    const float d2 = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+                    if (d2 < bd) { bd = d2; pos = c[u]; }
+                    else if (d2 == bd && pos >= 0 && c[u] != pos) { if (g.order[c[u]] < g.order[pos]) pos = c[u]; }
+                }
             }
         }
         gbd = fminf(gbd, bd);
@@ -875,7 +916,7 @@ __device__ __forceinline__ int nn_within_group(const BatchGrid& g, const SegGrid
         }
     }
     *d2out = bd;
-    return best;
+    return pos;
 }
 
 // Late ICP iterations: the jobs still running are the ones that do not converge (wrong assignments: sources with no target inside the
@@ -884,36 +925,42 @@ __device__ __forceinline__ int nn_within_group(const BatchGrid& g, const SegGrid
 template <int LPQ>
 __global__ __launch_bounds__(256) void ibl_icp_nn_group_kernel(BatchGrid g, const float4* __restrict__ pts, const int* __restrict__ job_off, int J,
                                                                const int* __restrict__ piece_off, const IcpState* __restrict__ st, float radius,
-                                                               float r2, int* __restrict__ nn_idx, float* __restrict__ nn_d2) {
-    const int j = blockIdx.y;
-    const IcpState& S = st[j];
-    if (S.done) return;
+                                                               float r2, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
+                                                               const int* __restrict__ act_list, const int* __restrict__ act_cnt) {
+    // grid (chunks of the largest source side, ICP_ACT_Y): block row y walks the ACTIVE jobs y, y + ICP_ACT_Y, ... of the list the previous
+    // iteration's update kernel wrote -- a (chunks, J) grid spent 40 us per launch on dispatching the ~90 000 blocks of finished jobs
+    const int n_act = *act_cnt;
     const int sub = threadIdx.x % LPQ;
-    const int p = job_off[j] + blockIdx.x * (256 / LPQ) + threadIdx.x / LPQ;
-    if (p >= job_off[j + 1]) return;                 // (whole groups leave together)
-    const int i = g.order[p];
-    const float4 s4 = pts[i];
-    double T[12], vs[3];
-    for (int t = 0; t < 12; ++t) T[t] = S.T[t];
-    xform_d(T, s4.x, s4.y, s4.z, vs);
-    float d2 = r2;
-    int best = -1;
+    for (int a = blockIdx.y; a < n_act; a += gridDim.y) {
+        const int j = act_list[a];
+        const IcpState& S = st[j];
+        const int p = job_off[j] + blockIdx.x * (256 / LPQ) + threadIdx.x / LPQ;
+        if (p >= job_off[j + 1]) continue;               // (whole groups leave together)
+        const int i = g.order[p];
+        const float4 s4 = pts[i];
+        double T[12], vs[3];
+        for (int t = 0; t < 12; ++t) T[t] = S.T[t];
+        xform_d(T, s4.x, s4.y, s4.z, vs);
+        float d2 = r2;
+        int pos = -1;
 #pragma unroll 1
-    for (int t = 0; t < 3; ++t) {
-        const int k = J + 3 * j + t;
-        if (piece_off[k + 1] > piece_off[k])      // (a lane keeps its own best from piece to piece; the group's best prunes)
-            best = nn_within_group<LPQ>(g, g.seg[k], (float)vs[0], (float)vs[1], (float)vs[2], radius, sub, best, &d2);
-    }
-    // (d2, index) minimum over the group; best = -1 (with d2 = r2) marks a lane that found nothing
+        for (int t = 0; t < 3; ++t) {
+            const int k = J + 3 * j + t;
+            if (piece_off[k + 1] > piece_off[k])      // (a lane keeps its own best from piece to piece; the group's best prunes)
+                pos = nn_within_group<LPQ>(g, g.seg[k], (float)vs[0], (float)vs[1], (float)vs[2], radius, sub, pos, &d2);
+        }
+        int best = pos >= 0 ? g.order[pos] : -1;
+        // (d2, index) minimum over the group; best = -1 (with d2 = r2) marks a lane that found nothing
 #pragma unroll
-    for (int off = 1; off < LPQ; off <<= 1) {
-        const float od = __shfl_xor(d2, off, 64);
-        const int ob = __shfl_xor(best, off, 64);
-        if (od < d2 || (od == d2 && ob >= 0 && (best < 0 || ob < best))) { d2 = od; best = ob; }
-    }
-    if (sub == 0) {
-        nn_idx[i] = best;
-        nn_d2[i] = d2;
+        for (int off = 1; off < LPQ; off <<= 1) {
+            const float od = __shfl_xor(d2, off, 64);
+            const int ob = __shfl_xor(best, off, 64);
+            if (od < d2 || (od == d2 && ob >= 0 && (best < 0 || ob < best))) { d2 = od; best = ob; }
+        }
+        if (sub == 0) {
+            nn_idx[i] = best;
+            nn_d2[i] = d2;
+        }
     }
 }
 
@@ -942,25 +989,29 @@ __global__ __launch_bounds__(256) void ibl_icp_nn_kernel(BatchGrid g, const floa
     for (int t = 0; t < 12; ++t) T[t] = S.T[t];
     xform_d(T, s4.x, s4.y, s4.z, vs);
     float d2 = r2;
-    int best = -1;
+    int pos = -1;
 #pragma unroll 1
     for (int t = 0; t < 3; ++t) {
         const int k = J + 3 * j + t;
-        if (piece_off[k + 1] > piece_off[k]) best = nn_within(g, g.seg[k], (float)vs[0], (float)vs[1], (float)vs[2], radius, best, &d2);
+        if (piece_off[k + 1] > piece_off[k]) pos = nn_within(g, g.seg[k], (float)vs[0], (float)vs[1], (float)vs[2], radius, pos, &d2);
     }
-    nn_idx[i] = best;
+    nn_idx[i] = pos >= 0 ? g.order[pos] : -1;
     nn_d2[i] = d2;
 }
 
-// grid (ICP_BPJ, J): the normal-equation / Kabsch moments of the correspondences found by ibl_icp_nn_kernel
+// grid (ICP_BPJ, J), or (ICP_BPJ, ICP_ACT_Y) over the active-job list (act_list != null): the normal-equation / Kabsch moments of the
+// correspondences found by ibl_icp_nn_kernel
 __global__ __launch_bounds__(256) void ibl_icp_step_kernel(const float4* __restrict__ pts, const float4* __restrict__ normals,
                                                            const float4* __restrict__ grad, const int* __restrict__ job_off, int J,
                                                            const IcpState* __restrict__ st, const int* __restrict__ nn_idx,
                                                            const float* __restrict__ nn_d2, int colored,
-                                                           double sl_g, double sl_p, double* __restrict__ partial /* [J][BPJ][NACC] */) {
-    const int j = blockIdx.y;
+                                                           double sl_g, double sl_p, double* __restrict__ partial /* [J][BPJ][NACC] */,
+                                                           const int* __restrict__ act_list, const int* __restrict__ act_cnt) {
+    const int n_act = act_list ? *act_cnt : J;
+    for (int a = blockIdx.y; a < n_act; a += gridDim.y) {
+    const int j = act_list ? act_list[a] : a;
     const IcpState& S = st[j];
-    if (S.done) return;
+    if (S.done) continue;
     const int sb = job_off[j], se = job_off[j + 1];
     double T[12];
     for (int t = 0; t < 12; ++t) T[t] = S.T[t];
@@ -1017,6 +1068,8 @@ __global__ __launch_bounds__(256) void ibl_icp_step_kernel(const float4* __restr
     if (threadIdx.x < ICP_NACC)
         partial[((int64_t)j * ICP_BPJ + blockIdx.x) * ICP_NACC + threadIdx.x] =
             ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+    __syncthreads();          // (sh is reused by the next job of this block row)
+    }
 }
 
 __device__ inline bool solve6_d(double A[6][6], double* b, double* x) {
@@ -1042,9 +1095,22 @@ __device__ inline bool solve6_d(double A[6][6], double* b, double* x) {
 }
 
 // wave per job: finish the reduction, convergence test, Gauss-Newton / Kabsch update
+// act_list / act_cnt: the active jobs of this iteration (null: all J, one block each); next_list / next_cnt (may be null): the jobs
+// still running after this update are appended for the next iteration (in any order: jobs are independent)
+__device__ __forceinline__ void icp_update_job(IcpState* __restrict__ st, int j, const int* __restrict__ job_off, const double* __restrict__ partial,
+                                               int colored, int max_iter, double rel_fitness, double rel_rmse, int* __restrict__ next_list,
+                                               int* __restrict__ next_cnt);
 __global__ __launch_bounds__(64) void ibl_icp_update_kernel(IcpState* __restrict__ st, int J, const int* __restrict__ job_off, const double* __restrict__ partial,
-                                      int colored, int max_iter, double rel_fitness, double rel_rmse) {
-    const int j = blockIdx.x;             // one wavefront per job: lane t folds moment t over the blocks (in block order), lane 0 solves
+                                      int colored, int max_iter, double rel_fitness, double rel_rmse, const int* __restrict__ act_list,
+                                      const int* __restrict__ act_cnt, int* __restrict__ next_list, int* __restrict__ next_cnt) {
+    const int n_act = act_list ? *act_cnt : J;
+    for (int a = blockIdx.x; a < n_act; a += gridDim.x)
+        icp_update_job(st, act_list ? act_list[a] : a, job_off, partial, colored, max_iter, rel_fitness, rel_rmse, next_list, next_cnt);
+}
+__device__ __forceinline__ void icp_update_job(IcpState* __restrict__ st, int j, const int* __restrict__ job_off, const double* __restrict__ partial,
+                                               int colored, int max_iter, double rel_fitness, double rel_rmse, int* __restrict__ next_list,
+                                               int* __restrict__ next_cnt) {
+    // one wavefront per job: lane t folds moment t over the blocks (in block order), lane 0 solves
     if (st[j].done) return;
     double mine = 0.0;
     if (threadIdx.x < ICP_NACC)
@@ -1093,6 +1159,7 @@ __global__ __launch_bounds__(64) void ibl_icp_update_kernel(IcpState* __restrict
     for (int i = 0; i < 16; ++i) S.T[i] = R[i];
     S.iter++;
     st[j] = S;
+    if (next_list) next_list[atomicAdd(next_cnt, 1)] = j;        // still running
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1680,7 +1747,10 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 const int nblk = round_size / 256;
                 const int n_tab = n_act * nblk;           // tables are indexed by (slot in the active list, block)
                 IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_act * round_size, s));
-                if (round_size >= 16384)
+                // 16 k-hypothesis blocks amortise the dense Kabsch pass best, but a round of few jobs (or the 32 k round of all of them) is a few
+                // hundred such blocks -- under two per CU, each ~120 us long: those rounds run as 4 k blocks (same flags: a hypothesis does not
+                // know its block)
+                if (round_size >= 16384 && (int64_t)(round_size / 16384) * n_act >= RANSAC_WIDE_MIN_BLOCKS)
                     hipLaunchKernelGGL(ibl_ransac_flag_kernel<16>, dim3(round_size / 16384, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
                                        (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
                                        blk_cnt, active);
@@ -1753,19 +1823,31 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         int max_side = 0;
         for (int j = 0; j < J; ++j) max_side = std::max(max_side, job_off[j + 1] - job_off[j]);
         const unsigned chunks = (unsigned)std::max(1, (max_side + 255) / 256);
+        // from ICP_GROUP_FROM on the kernels walk the list of jobs still running (written by the previous update: list it & 1, count
+        // act_cnt[it]) on a grid of ICP_ACT_Y block rows instead of one row per job
+        int *act_list, *act_cnt;
+        IBL_ARENA(act_list, int, 2 * (int64_t)J + 64);
+        IBL_ARENA(act_cnt, int, max_iter + 8);
+        IBL_HIP_CHECK(hipMemsetAsync(act_cnt, 0, sizeof(int) * (max_iter + 8), s));
+        const unsigned act_y = (unsigned)std::min(J, ICP_ACT_Y);
         for (int it = 0; it <= max_iter; ++it) {
-            if (it < ICP_GROUP_FROM)
+            const bool listed = it >= ICP_GROUP_FROM;
+            const int* cur_list = listed ? act_list + (size_t)(it & 1) * J : nullptr;
+            const int* cur_cnt = listed ? act_cnt + it : nullptr;
+            int* nxt_list = it + 1 >= ICP_GROUP_FROM ? act_list + (size_t)((it + 1) & 1) * J : nullptr;
+            int* nxt_cnt = it + 1 >= ICP_GROUP_FROM ? act_cnt + it + 1 : nullptr;
+            if (!listed)
                 hipLaunchKernelGGL(ibl_icp_nn_kernel, dim3(chunks, J), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is, (float)max_dist_icp,
                                    (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
             else
-                hipLaunchKernelGGL(ibl_icp_nn_group_kernel<8>, dim3(chunks * 8, J), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is,
-                                   (float)max_dist_icp, (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
+                hipLaunchKernelGGL(ibl_icp_nn_group_kernel<8>, dim3(chunks * 8, act_y), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is,
+                                   (float)max_dist_icp, (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2, cur_list, cur_cnt);
             IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, P, normals, grad, d_job_off, J, is, icp_nn, icp_d2,
-                               colored ? 1 : 0, sqrt(lambda_geometric), sqrt(1.0 - lambda_geometric), partial);
+            hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, listed ? act_y : (unsigned)J), dim3(256), 0, s, P, normals, grad, d_job_off, J, is, icp_nn,
+                               icp_d2, colored ? 1 : 0, sqrt(lambda_geometric), sqrt(1.0 - lambda_geometric), partial, cur_list, cur_cnt);
             IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL(ibl_icp_update_kernel, dim3(J), dim3(64), 0, s, is, J, d_job_off, partial, colored ? 1 : 0, max_iter,
-                               1e-6, 1e-6);
+            hipLaunchKernelGGL(ibl_icp_update_kernel, dim3(listed ? act_y : (unsigned)J), dim3(64), 0, s, is, J, d_job_off, partial, colored ? 1 : 0, max_iter,
+                               1e-6, 1e-6, cur_list, cur_cnt, nxt_list, nxt_cnt);
             IBL_LAUNCH_CHECK();
         }
     }
