@@ -48,7 +48,9 @@ typedef __attribute__((ext_vector_type(16))) float fm_f32x16;
 #define FM_ROWB 112              // LDS bytes per row: 48 fp16 + 16 pad (2-way instead of 4-way bank conflicts on ds_read_b128)
 #define FM_C 1.0e-3f             // E = FM_C (|q|^2 + |t|^2)
 #define FM_NS 8.0f               // norms are stored divided by 8 (|x|^2 reaches 1.2e5, fp16 ends at 65 504) against a constant 8
+#ifndef FM_NQ
 #define FM_NQ 2                  // 32-query tiles per wave (they share every database fragment read)
+#endif
 #define FM_P1_STRIDE 2           // pass 1 visits one database chunk in FM_P1_STRIDE (ibl_feat_search_mfma)
 #define FM_QUEUE 256             // per-wave candidate queue, flushed when fewer than 64 slots (one append step) are left
 

@@ -1681,10 +1681,14 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
                 const int j = nbr_idx[(int64_t)si * K + t];
                 const double dist = (double)nbr_d2[(int64_t)si * K + t];
                 const int kj = nbr_cnt[j];
-                const unsigned int* src = reinterpret_cast<const unsigned int*>(spfh_cnt + (int64_t)j * 36);
+                // a 36-byte row as 16 + 16 + 4 bytes (rows are 4-byte aligned: the under-aligned vector type makes these two
+                // global_load_dwordx4 + one dword instead of nine dword gathers per row)
+                typedef uint4 __attribute__((aligned(4))) uint4_a4;
+                const unsigned char* src = spfh_cnt + (int64_t)j * 36;
+                const uint4 r0 = *reinterpret_cast<const uint4_a4*>(src), r1 = *reinterpret_cast<const uint4_a4*>(src + 16);
+                const unsigned r2w = *reinterpret_cast<const unsigned*>(src + 32);
                 unsigned int* dst = reinterpret_cast<unsigned int*>(S.cnt[r]);
-#pragma unroll
-                for (int w = 0; w < 9; ++w) dst[w] = src[w];
+                dst[0] = r0.x; dst[1] = r0.y; dst[2] = r0.z; dst[3] = r0.w; dst[4] = r1.x; dst[5] = r1.y; dst[6] = r1.z; dst[7] = r1.w; dst[8] = r2w;
                 // SPFH(j)[b] / d2 = count x (increment / d2) in double (Open3D keeps its histograms in double; oracle_fpfh likewise): one
                 // division per neighbour, one fma per (neighbour, bin); a zero weight or an empty bin adds an exact zero
                 S.w[r] = (j == si || dist == 0.0 || kj <= 1) ? 0.0 : (100.0 / (double)(kj - 1)) / dist;

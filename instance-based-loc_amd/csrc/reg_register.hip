@@ -40,6 +40,9 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
 #endif
 // (32 lanes per point from iteration 11 on measured 100 us per launch: the grid of 32x the blocks, nearly all of finished jobs, costs
 // more to schedule than the shorter walk saves)
+#ifndef ICP_LPQ
+#define ICP_LPQ 8            // lanes per source point of ibl_icp_nn_group_kernel
+#endif
 #define ICP_ACT_Y 32      // block rows of the ICP kernels once they walk the active-job list (iterations >= ICP_GROUP_FROM >= 1)
 static_assert(ICP_GROUP_FROM >= 1, "the first active-job list is written by the update of iteration ICP_GROUP_FROM - 1");
 #define ICP_BPJ 8        // blocks per job in the ICP / evaluation reductions (each ends in a 29-value fp64 block reduction)
@@ -1840,7 +1843,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 hipLaunchKernelGGL(ibl_icp_nn_kernel, dim3(chunks, J), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is, (float)max_dist_icp,
                                    (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2);
             else
-                hipLaunchKernelGGL(ibl_icp_nn_group_kernel<8>, dim3(chunks * 8, act_y), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is,
+                hipLaunchKernelGGL(ibl_icp_nn_group_kernel<ICP_LPQ>, dim3(chunks * ICP_LPQ, act_y), dim3(256), 0, s, gC, P, d_job_off, J, d_piece_off, is,
                                    (float)max_dist_icp, (float)(max_dist_icp * max_dist_icp), icp_nn, icp_d2, cur_list, cur_cnt);
             IBL_LAUNCH_CHECK();
             hipLaunchKernelGGL(ibl_icp_step_kernel, dim3(ICP_BPJ, listed ? act_y : (unsigned)J), dim3(256), 0, s, P, normals, grad, d_job_off, J, is, icp_nn,
