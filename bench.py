@@ -163,7 +163,7 @@ def build_workload(args, rank, world_size, device):
     # --shard-clouds: this rank keeps the clouds / cached features / evaluation grid of its instance range only; registration jobs are
     # routed between the ranks (ibloc_amd/routing.py).  At one rank it runs the routed path with every instance local.
     mem = MemoryShard(ctx, list(mem_emb), world.points if args.register else None, colors=world.colors if args.register else None,
-                      device=device, shard=shard, shard_clouds=args.shard_clouds)
+                      device=device, shard=shard, shard_clouds=args.shard_clouds, compact_features=args.compact_features)
     # host cores are shared by the ranks of the node: the assignment search takes its share, at most 16 threads
     cores = host_cores()
     eng = LocaliseEngine(mem, enc, assign_threads=max(1, min(16, cores // max(1, world_size))), rows_cap=args.frames * 7, comm=comm)
@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--layout", default="auto", choices=["auto", "sharded", "replicated"],
                     help="N > 1: `sharded` (default) = embedding memory sharded by instance range + RCCL exchange of the per-shard top-k "
                     "candidate lists (north star); `replicated` = every rank holds the whole memory, no data-path collective")
+    ap.add_argument("--compact-features", action="store_true", help="keep the memory's resident instance features without their fp16 search "
+                    "operands (168 instead of 264 bytes per point; the feature search converts while it stages)")
     ap.add_argument("--spacing", type=float, default=2.5, help="grid spacing of the synthetic memory's objects in metres (2.5: separated "
                     "objects; ~0.7: adjacent objects whose neighbourhoods overlap, so cross-instance features are recomputed)")
     ap.add_argument("--ransac-budget", type=int, default=100000, help="hypotheses per job of the fixed-budget RANSAC figure (0 = skip)")
@@ -493,6 +495,7 @@ def main():
                           "are too sparse to survive the radius-outlier removal)" % args.spacing if args.register else ""),
                        "frames_per_step_per_gpu": args.frames, "memory_instances": args.memory,
                        "points_per_object": args.points, "object_spacing_m": args.spacing,
+                       "resident_feature_bytes_per_point": 168 if args.compact_features else 264,
                        "parallelism": f"frames-dp{world_size}" + ("+memory-shard%d(%s)" % (world_size, args.comm) if args.shard_memory else "+memory-replicated")
                        + ("+cloud-shard%d" % world_size if args.shard_clouds else ""),
                        "rccl_ranks": (eng.exchange.comm.world if eng.exchange is not None and eng.exchange.comm is not None

@@ -178,37 +178,26 @@ extern "C" int ibl_normals_fpfh_batch(ibl_reg_ctx* ctx, const float* pts4, const
 // ------------------------------------------------------------------------------------------------
 // registration features of a batch of clouds (shared by the instance cache and by ibl_register_batch_cached)
 // ------------------------------------------------------------------------------------------------
-// every FPFH row once more as the 48 fp16 search operands of reg_featnn.hip (layout and error budget in its header), and the squared
-// norm of the CENTRED row.  Centring (round 3): distances do not change when the same constant vector is subtracted from every row, the
-// filter's error bound C (|q|^2 + |t|^2) does -- FPFH rows share a strong common shape (each of the three histograms sums to 200 and
-// peaks at its centre bin on smooth surfaces), and with that shape removed the squared norms drop to 0.33 - 0.44 of the raw ones (the
-// synthetic objects and the reference's own saved objects alike), the band by as much.  FM_MU is a fixed table (integers, in matching
-// order): any constant is correct, this one is a rounded mean over those objects.
-__constant__ float FM_MU[33] = {87.f, 46.f, 101.f, 26.f, 28.f, 17.f, 26.f, 26.f, 17.f, 14.f, 21.f, 7.f, 14.f, 19.f, 7.f, 8.f, 14.f,
-                                6.f,  8.f,  13.f,  6.f,  5.f,  11.f, 6.f,  5.f,  10.f, 6.f,  3.f,  7.f,  14.f, 3.f, 6.f,  14.f};
+// every FPFH row once more as the 48 fp16 search operands of reg_featnn.hip (layout, centring and error budget in its header and at
+// fm_operand_piece, reg_common.h), and the squared norm of the CENTRED row.  split may be null (instance features kept without their
+// operand rows: 168 instead of 264 resident bytes per point; the search then builds the pieces from the fp32 rows as it stages them).
 __global__ __launch_bounds__(256) void ibl_fpfh_half_kernel(const float* __restrict__ fpfh, int n, unsigned short* __restrict__ split,
                                                             float* __restrict__ norm) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float* __restrict__ x = fpfh + (int64_t)i * 33;
-    _Float16 row[48];
-    float a = 0.0f;
-    for (int k = 0; k < 33; ++k) { const float v = x[k] - FM_MU[k]; row[k] = (_Float16)v; a = __builtin_fmaf(v, v, a); }
+    const float a = fm_centred_norm(x);
     norm[i] = a;
-    const float w = a * 0.125f;                                   // |y|^2 / 8 as fp16 hi + lo against the constant 8 of the other side
-    const _Float16 nh = (_Float16)w, nl = (_Float16)(w - (float)nh);
-    // C |y|^2 + the absolute slack (a centred row can be small: components and norm terms in fp16's subnormal range are rounded to
-    // 2^-25 absolute, not 2^-11 relative -- reg_featnn.hip header), rounded UP (the bound must not shrink)
-    const float cw = 1.0e-3f * a + 4.0e-3f;
-    _Float16 cu = (_Float16)cw;
-    if ((float)cu < cw) cu = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, cu) + 1));
-    row[33] = (_Float16)8.0f; row[34] = (_Float16)8.0f; row[35] = nh; row[36] = nl; row[37] = cu;
-    for (int k = 38; k < 48; ++k) row[k] = (_Float16)0.0f;
+    if (!split) return;
     uint4* dst = reinterpret_cast<uint4*>(split + (int64_t)i * 48);
 #pragma unroll
     for (int pc = 0; pc < 6; ++pc) {
+        float x8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x8[e] = 8 * pc + e < 33 ? x[8 * pc + e] : 0.0f;
+        const fm_piece_t r = fm_operand_piece(x8, a, pc);
         uint4 v;
-        __builtin_memcpy(&v, &row[8 * pc], 16);
+        __builtin_memcpy(&v, &r, 16);
         dst[pc] = v;
     }
 }
@@ -252,7 +241,7 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
                                                 fpfh, 1, ctx->d_status, s);
         else st = ibl_launch_fpfh(ctx, gB, P, normals, seg_off_dev, n, voxel_size * 5, 100, spfh, nbr_idx, nbr_d2, nbr_cnt, fpfh, 1, ctx->d_status, s);
         if (st) return st;
-        if (fpfh_split && fpfh_norm) {
+        if (fpfh_norm) {
             hipLaunchKernelGGL(ibl_fpfh_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fpfh, n, fpfh_split, fpfh_norm);
             IBL_LAUNCH_CHECK();
         }
@@ -272,7 +261,7 @@ int ibl_features_on_batch(ibl_reg_ctx* ctx, const float4* P, const int* seg_off_
 extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, const int32_t* seg_off_dev, const int32_t* seg_off_host,
                                            int n_seg, double voxel_size, double grad_radius, float* normals4, float* fpfh,
                                            uint16_t* fpfh_split, float* fpfh_norm, float* grad4, float* bbox_host, void* stream) {
-    if (!ctx || !pts4 || !seg_off_dev || !normals4 || !fpfh || !fpfh_split || !fpfh_norm || voxel_size <= 0)
+    if (!ctx || !pts4 || !seg_off_dev || !normals4 || !fpfh || !fpfh_norm || voxel_size <= 0)
         return ibl_set_error(IBL_ERR_ARG, "ibl_instance_features_batch: bad argument");
     if (grad4 && grad_radius <= 0) return ibl_set_error(IBL_ERR_ARG, "ibl_instance_features_batch: colour gradients need grad_radius > 0");
     int st = check_seg(seg_off_host, n_seg, "ibl_instance_features_batch");
@@ -310,7 +299,7 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
         }
         const int cnt = off_host[ns];
         st = ibl_features_on_batch(ctx, P + o0, off_dev, off_host, ns, bbox_host + 6 * (size_t)s0, voxel_size, grad_radius, 0, grad4 ? cnt : 0,
-                                   reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33, fpfh_split + (int64_t)o0 * 48,
+                                   reinterpret_cast<float4*>(normals4) + o0, fpfh + (int64_t)o0 * 33, fpfh_split ? fpfh_split + (int64_t)o0 * 48 : nullptr,
                                    fpfh_norm + o0, grad4 ? reinterpret_cast<float4*>(grad4) + o0 : nullptr, s);
         if (st) return st;
         s0 = s1;

@@ -115,6 +115,7 @@ int ibl_launch_bbox(const float4* pts, const int* seg_off_dev, int n_seg, float*
 
 // feature arrays the registration driver reads in place: [0] detected-pool instance features, [1] memory-pool instance
 // features, [2] groups recomputed in the context of their job
+// (split[k] may be null -- an instance-feature set kept without its operand rows: the search then builds them from fpfh[k] / norm[k])
 struct FeatSources { const float4* normals[3]; const float* fpfh[3]; const float4* grad[3]; const unsigned short* split[3]; const float* norm[3]; };
 // one (query instance, database instance) nearest-neighbour search; kind = FeatSources index, src = point offset there,
 // out = offset of the query instance's results in the pair output arrays
@@ -131,6 +132,45 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
 // device helpers
 // ------------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// ---- the fp16 search operands of the feature search (reg_featnn.hip; layout and error budget in its header) ----
+// The centring constant: distances do not change when the same vector is subtracted from every row, the filter's error bound
+// C (|q|^2 + |t|^2) does -- FPFH rows share a strong common shape (each of the three histograms sums to 200 and peaks at its centre bin on
+// smooth surfaces), and with it removed the squared norms drop to 0.33 - 0.44 of the raw ones on 5 000-point objects (the synthetic ones
+// and the reference's own saved objects alike; 0.7 on sparser clouds), the band by as much.  A fixed table (integers, in matching
+// order): any constant is correct, this one is a rounded mean over those objects.
+__device__ __constant__ const float FM_MU[33] = {87.f, 46.f, 101.f, 26.f, 28.f, 17.f, 26.f, 26.f, 17.f, 14.f, 21.f, 7.f, 14.f, 19.f, 7.f, 8.f, 14.f,
+                                                 6.f,  8.f,  13.f,  6.f,  5.f,  11.f, 6.f,  5.f,  10.f, 6.f,  3.f,  7.f,  14.f, 3.f, 6.f,  14.f};
+typedef __attribute__((ext_vector_type(8))) _Float16 fm_piece_t;
+// sixteen bytes at a 4-byte aligned address (rows of 33 floats, 36-byte histogram rows): one global_load_dwordx4
+struct __attribute__((aligned(4))) ibl_u4_a4 { unsigned x, y, z, w; };
+// squared norm of the centred row (fp32 fmaf chain in matching order)
+__device__ __forceinline__ float fm_centred_norm(const float* __restrict__ x) {
+    float a = 0.0f;
+    for (int k = 0; k < 33; ++k) { const float v = x[k] - FM_MU[k]; a = __builtin_fmaf(v, v, a); }
+    return a;
+}
+// 16-byte piece `pc` (0..5) of the operand row [x_0 .. x_32 | 8 8 | nh nl | cu | 0 ...] of a feature row x with centred norm a:
+// nh + nl = a / 8 as fp16 hi + lo (against the constant 8 of the other side), cu = 1e-3 a + 4e-3 rounded UP (the bound must not
+// shrink; the absolute term covers centred components and norm terms in fp16's subnormal range, rounded to 2^-25 absolute).
+// x8: the eight floats x[8 pc .. 8 pc + 7] (only x8[0] is read for pc = 4, none for pc = 5).
+__device__ __forceinline__ fm_piece_t fm_operand_piece(const float* x8, float a, int pc) {
+    fm_piece_t r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.0f;
+    if (pc < 4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (_Float16)(x8[e] - FM_MU[8 * pc + e]);
+    } else if (pc == 4) {
+        const float w = a * 0.125f;
+        const _Float16 nh = (_Float16)w, nl = (_Float16)(w - (float)nh);
+        const float cw = 1.0e-3f * a + 4.0e-3f;
+        _Float16 cu = (_Float16)cw;
+        if ((float)cu < cw) cu = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, cu) + 1));
+        r[0] = (_Float16)(x8[0] - FM_MU[32]);
+        r[1] = (_Float16)8.0f; r[2] = (_Float16)8.0f; r[3] = nh; r[4] = nl; r[5] = cu;
+    }
+    return r;
+}
 __device__ __forceinline__ int seg_of(const int* __restrict__ seg_off, int n_seg, int i) {
     int lo = 0, hi = n_seg;   // find s with seg_off[s] <= i < seg_off[s+1]
     while (hi - lo > 1) {

@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "reg_common.h"
 
@@ -70,7 +71,10 @@ __device__ __forceinline__ void fm_split_norm(float v, _Float16* h, _Float16* l)
 // grid (query tiles of 128 FM_NQ, pairs); PASS 1: up[] ; PASS 2: candidates.  Operands come from the instance features
 // (fpfh_split: 48 fp16 per row, laid out as in the file header).  Database chunks of 32 rows are copied to LDS (16-byte pieces,
 // fetched into registers one chunk ahead); every wave holds its 32 queries as the B operand in registers.
-template <int PASS, bool INDEXED>
+// CONV: some instance-feature set of the call has no resident operand rows (src.split[kind] == null: compact features, 168 instead of 264
+// bytes per point): its pieces are built from the fp32 rows (fm_operand_piece: the same bits ibl_fpfh_half_kernel would have stored) --
+// the queries' once per wave, the database's as a chunk is stashed (the raw floats wait in registers where the stored piece would).
+template <int PASS, bool INDEXED, bool CONV>
 __global__ __launch_bounds__(256, 2) void ibl_feat_mfma_kernel(const FeatPair* __restrict__ pairs, FeatSources src, float* __restrict__ up,
                                                             FmCand* __restrict__ cand, unsigned long long* __restrict__ n_cand, int cand_cap,
                                                             const int* __restrict__ need_pos, const int* __restrict__ need_list, int out0, int cstride) {
@@ -84,6 +88,9 @@ __global__ __launch_bounds__(256, 2) void ibl_feat_mfma_kernel(const FeatPair* _
     const int n = lane & 31, kg = lane >> 5;
     const uint4* __restrict__ qs = reinterpret_cast<const uint4*>(src.split[P.qkind] + (int64_t)P.qsrc * 48);      // 6 pieces per row
     const uint4* __restrict__ ds = reinterpret_cast<const uint4*>(src.split[P.dkind] + (int64_t)P.dsrc * 48);
+    const bool q_has_split = !CONV || src.split[P.qkind] != nullptr, d_has_split = !CONV || src.split[P.dkind] != nullptr;
+    const float* __restrict__ dfp = src.fpfh[P.dkind] + (int64_t)P.dsrc * 33;
+    const float* __restrict__ dnorm = src.norm[P.dkind] + P.dsrc;
     constexpr float SGN = PASS == 1 ? 1.0f + FM_C : 1.0f - FM_C;
 
     // this wave's FM_NQ x 32 queries as B operands (one set of database fragments serves them all): lane (n, kg) holds terms
@@ -100,8 +107,18 @@ __global__ __launch_bounds__(256, 2) void ibl_feat_mfma_kernel(const FeatPair* _
         qi[u] = INDEXED ? need_list[l0 + qc] - (P.out - out0) : qc;
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
-            const uint4 h = qs[(int64_t)qi[u] * 6 + 2 * s3 + kg];
-            __builtin_memcpy(&qh[u][s3], &h, 16);
+            if (CONV && !q_has_split) {
+                const int pc = 2 * s3 + kg;
+                const float* __restrict__ row = src.fpfh[P.qkind] + ((int64_t)P.qsrc + qi[u]) * 33;
+                float x8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x8[e] = 8 * pc + e < 33 ? row[8 * pc + e] : 0.0f;
+                const fm_piece_t r = fm_operand_piece(x8, src.norm[P.qkind][P.qsrc + qi[u]], pc);
+                __builtin_memcpy(&qh[u][s3], &r, 16);
+            } else {
+                const uint4 h = qs[(int64_t)qi[u] * 6 + 2 * s3 + kg];
+                __builtin_memcpy(&qh[u][s3], &h, 16);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) qh[u][s3][e] = (_Float16)-2.0f * qh[u][s3][e];      // exact (a power of two)
         }
@@ -122,6 +139,9 @@ __global__ __launch_bounds__(256, 2) void ibl_feat_mfma_kernel(const FeatPair* _
     const int n_chunks = (P.dcnt + FM_DT - 1) / FM_DT;
     constexpr int NPIECE = FM_DT * 6, PPT = (NPIECE + 255) / 256;          // 16-byte pieces of a chunk, per thread
     uint4 pre[PPT];
+    [[maybe_unused]] uint4 pre2[CONV ? PPT : 1];     // CONV: a piece's eight raw floats (pre, pre2) until the chunk is stashed
+    [[maybe_unused]] float prn[CONV ? PPT : 1];      //       and, for piece 4, the row's centred norm
+    [[maybe_unused]] bool raw[CONV ? PPT : 1];       //       (false: a ready-made piece -- a stored one, or the filler of a row past the end)
     int pr[PPT], pp[PPT];
 #pragma unroll
     for (int v = 0; v < PPT; ++v) { pre[v] = make_uint4(0, 0, 0, 0); pr[v] = (tid + 256 * v) / 6; pp[v] = (tid + 256 * v) - pr[v] * 6; }
@@ -129,14 +149,39 @@ __global__ __launch_bounds__(256, 2) void ibl_feat_mfma_kernel(const FeatPair* _
 #pragma unroll
         for (int v = 0; v < PPT; ++v)
             if (tid + 256 * v < NPIECE) {
-                if (t0 + pr[v] < P.dcnt) pre[v] = ds[(int64_t)(t0 + pr[v]) * 6 + pp[v]];
-                else pre[v] = pp[v] == 4 ? make_uint4(0, 0x7BFFu << 16, 0x7BFFu, 0) : make_uint4(0, 0, 0, 0);      // terms 35, 36 = 65 504: a bound of 1.05e6 > 2 N
+                if (CONV) raw[v] = false;
+                if (t0 + pr[v] < P.dcnt) {
+                    if (CONV && !d_has_split) {
+                        raw[v] = true;
+                        const float* row = dfp + (int64_t)(t0 + pr[v]) * 33 + 8 * pp[v];
+                        if (pp[v] < 4) {                                   // (a 132-byte row is 4-byte aligned)
+                            const ibl_u4_a4 lo = *reinterpret_cast<const ibl_u4_a4*>(row), hi = *reinterpret_cast<const ibl_u4_a4*>(row + 4);
+                            pre[v] = make_uint4(lo.x, lo.y, lo.z, lo.w);
+                            pre2[v] = make_uint4(hi.x, hi.y, hi.z, hi.w);
+                        }
+                        else if (pp[v] == 4) { pre[v].x = __float_as_uint(row[0]); prn[v] = dnorm[t0 + pr[v]]; }
+                    } else {
+                        pre[v] = ds[(int64_t)(t0 + pr[v]) * 6 + pp[v]];
+                    }
+                } else {
+                    // terms 35, 36 = 65 504: a bound of 1.05e6 > 2 N
+                    pre[v] = pp[v] == 4 ? make_uint4(0, 0x7BFFu << 16, 0x7BFFu, 0) : make_uint4(0, 0, 0, 0);
+                }
             }
     };
     auto stash = [&](FmTile& T) {
 #pragma unroll
         for (int v = 0; v < PPT; ++v)
-            if (tid + 256 * v < NPIECE) *reinterpret_cast<uint4*>(T.rows + pr[v] * FM_ROWB + 16 * pp[v]) = pre[v];
+            if (tid + 256 * v < NPIECE) {
+                uint4 out = pre[v];
+                if (CONV && raw[v]) {
+                    float x8[8] = {__uint_as_float(pre[v].x), __uint_as_float(pre[v].y), __uint_as_float(pre[v].z), __uint_as_float(pre[v].w),
+                                   __uint_as_float(pre2[v].x), __uint_as_float(pre2[v].y), __uint_as_float(pre2[v].z), __uint_as_float(pre2[v].w)};
+                    const fm_piece_t r = fm_operand_piece(x8, prn[v], pp[v]);
+                    __builtin_memcpy(&out, &r, 16);
+                }
+                *reinterpret_cast<uint4*>(T.rows + pr[v] * FM_ROWB + 16 * pp[v]) = out;
+            }
     };
     __shared__ int2 queue[PASS == 2 ? 4 : 1][PASS == 2 ? FM_QUEUE : 1];
     int qcount = 0;                                  // wave-uniform
@@ -284,18 +329,23 @@ int ibl_feat_search_mfma(ibl_reg_ctx* ctx, const FeatPair* d_pairs, int n_pairs,
     // pass 1 on every FM_P1_STRIDE-th chunk of the database: 1 / stride of a pass for a bound that is the stride-th smallest distance or so
     static int p1s = -1;
     if (p1s < 0) { const char* e = getenv("IBL_FEAT_P1_STRIDE"); p1s = e ? std::max(1, atoi(e)) : FM_P1_STRIDE; }
+    bool conv = false;                  // a feature set without resident operand rows takes part
+    for (int k = 0; k < 3; ++k) conv = conv || (src.fpfh[k] && !src.split[k]);
     for (int p0 = 0; p0 < n_pairs; p0 += 32768) {
         const unsigned np = (unsigned)std::min(32768, n_pairs - p0);
         const dim3 grid((max_q + 128 * FM_NQ - 1) / (128 * FM_NQ), np);
-        if (indexed) {
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, true>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, p1s);
-            IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, true>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, 1);
-        } else {
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, false>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, p1s);
-            IBL_LAUNCH_CHECK();
-            hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, false>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, 1);
-        }
+        auto passes = [&](auto cv) {
+            constexpr bool CV = decltype(cv)::value;
+            if (indexed) {
+                hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, true, CV>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, p1s);
+                hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, true, CV>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, 1);
+            } else {
+                hipLaunchKernelGGL((ibl_feat_mfma_kernel<1, false, CV>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, p1s);
+                hipLaunchKernelGGL((ibl_feat_mfma_kernel<2, false, CV>), grid, dim3(256), 0, s, d_pairs + p0, src, up0, cand, n_cand, cand_cap, need_pos, need_list, out0, 1);
+            }
+        };
+        if (conv) passes(std::true_type{});
+        else passes(std::false_type{});
         IBL_LAUNCH_CHECK();
     }
     if (getenv("IBL_TIMING") && atoi(getenv("IBL_TIMING")) >= 2) {

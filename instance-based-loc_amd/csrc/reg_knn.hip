@@ -1681,11 +1681,10 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
                 const int j = nbr_idx[(int64_t)si * K + t];
                 const double dist = (double)nbr_d2[(int64_t)si * K + t];
                 const int kj = nbr_cnt[j];
-                // a 36-byte row as 16 + 16 + 4 bytes (rows are 4-byte aligned: the under-aligned vector type makes these two
+                // a 36-byte row as 16 + 16 + 4 bytes (rows are 4-byte aligned: the 4-byte aligned struct makes these two
                 // global_load_dwordx4 + one dword instead of nine dword gathers per row)
-                typedef uint4 __attribute__((aligned(4))) uint4_a4;
                 const unsigned char* src = spfh_cnt + (int64_t)j * 36;
-                const uint4 r0 = *reinterpret_cast<const uint4_a4*>(src), r1 = *reinterpret_cast<const uint4_a4*>(src + 16);
+                const ibl_u4_a4 r0 = *reinterpret_cast<const ibl_u4_a4*>(src), r1 = *reinterpret_cast<const ibl_u4_a4*>(src + 16);
                 const unsigned r2w = *reinterpret_cast<const unsigned*>(src + 32);
                 unsigned int* dst = reinterpret_cast<unsigned int*>(S.cnt[r]);
                 dst[0] = r0.x; dst[1] = r0.y; dst[2] = r0.z; dst[3] = r0.w; dst[4] = r1.x; dst[5] = r1.y; dst[6] = r1.z; dst[7] = r1.w; dst[8] = r2w;

@@ -1372,7 +1372,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
             const ibl_instance_features* feat[2] = {det_features, mem_features};
             for (int pl = 0; pl < 2; ++pl) {
                 if (!feat[pl]) continue;
-                if (!feat[pl]->normals4 || !feat[pl]->fpfh || !feat[pl]->fpfh_split || !feat[pl]->fpfh_norm || !feat[pl]->bbox)
+                if (!feat[pl]->normals4 || !feat[pl]->fpfh || !feat[pl]->fpfh_norm || !feat[pl]->bbox)       // (fpfh_split may be null: compact features)
                     return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_cached: instance features with null arrays");
                 if (fabs(feat[pl]->voxel_size - voxel_size) > 1e-12 * voxel_size)
                     return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch_cached: instance features were built for voxel_size %g, not %g",

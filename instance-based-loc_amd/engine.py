@@ -51,8 +51,9 @@ class MemoryShard:
     that range), registration jobs are routed between the ranks and the evaluation is reduced over them (routing.py)."""
 
     def __init__(self, ctx: RegContext, embeddings, clouds=None, colors=None, intensities=None, eval_threshold=0.02, device="cuda",
-                 shard=None, shard_clouds=False):
+                 shard=None, shard_clouds=False, compact_features=False):
         self.ctx = ctx
+        self.compact_features = bool(compact_features)     # resident instance features without their fp16 operand rows (168 B / point)
         self.device = torch.device(device)
         self.M = len(embeddings)
         self.shard = shard
@@ -86,10 +87,11 @@ class MemoryShard:
 
     def features(self, voxel_size, local_dist_factor):
         """Normals, FPFH and colour gradients of every memory instance for these registration parameters: computed on first
-        use, then resident in HBM (1.8 GB per 1 000 instances of 5 000 points) for every later query."""
+        use, then resident in HBM (1.3 GB per 1 000 instances of 5 000 points; 0.84 GB with compact_features) for every later query."""
         key = (float(voxel_size), float(local_dist_factor))
         if key not in self._features:
-            self._features[key] = instance_features_batch(self.ctx, self.clouds, voxel_size, 2.0 * (voxel_size * local_dist_factor))
+            self._features[key] = instance_features_batch(self.ctx, self.clouds, voxel_size, 2.0 * (voxel_size * local_dist_factor),
+                                                          compact=self.compact_features)
         return self._features[key]
 
     def close(self):
@@ -382,8 +384,9 @@ class LocaliseEngine:
         from .routing import InstanceStore, routed_register
         mem = self.memory
         assert det_feat is not None and mem_feat is not None, "sharded clouds need reuse_features (the cached instance features travel)"
-        arrays = {"pts": mem.clouds.pts4, "normals": mem_feat.normals, "fpfh": mem_feat.fpfh, "fpfh_split": mem_feat.fpfh_split,
-                  "fpfh_norm": mem_feat.fpfh_norm}
+        arrays = {"pts": mem.clouds.pts4, "normals": mem_feat.normals, "fpfh": mem_feat.fpfh, "fpfh_norm": mem_feat.fpfh_norm}
+        if mem_feat.fpfh_split is not None:                 # (compact features travel without their operand rows)
+            arrays["fpfh_split"] = mem_feat.fpfh_split
         if mem_feat.grad is not None:
             arrays["grad"] = mem_feat.grad
         store = InstanceStore(mem.lo, mem.clouds.seg_off_host, arrays, {"bbox": mem_feat.bbox})
@@ -399,7 +402,7 @@ class LocaliseEngine:
                                         torch.cat([det_feat.fpfh_norm[:clean.n], extra.fpfh_norm]), None,
                                         np.concatenate([det_feat.bbox[:clean.n_seg], extra.bbox]), voxel, 0.0)
             mem_pool = CloudBatch(arr["pts"].contiguous(), np.asarray(mem_off).astype(np.int32))
-            mf = InstanceFeatures(arr["normals"].contiguous(), arr["fpfh"].contiguous(), arr["fpfh_split"].contiguous(),
+            mf = InstanceFeatures(arr["normals"].contiguous(), arr["fpfh"].contiguous(), arr["fpfh_split"].contiguous() if "fpfh_split" in arr else None,
                                   arr["fpfh_norm"].contiguous(), arr["grad"].contiguous() if "grad" in arr else None,
                                   np.ascontiguousarray(per_inst["bbox"]), mem_feat.voxel_size, mem_feat.grad_radius)
             r = register_batch(ctx, det_pool, mem_pool, js, jt, voxel, gdf, ldf, seed=seed, ransac_max_iter=ransac_max_iter,

@@ -150,7 +150,8 @@ class _FeatStruct(C.Structure):
 
 class InstanceFeatures:
     """Registration features of every cloud of a batch, resident on the device (ibl_instance_features): normals,
-    FPFH and (for memory instances) colour gradients, plus host bounding boxes."""
+    FPFH and (for memory instances) colour gradients, plus host bounding boxes.  fpfh_split is None for COMPACT features (168 instead
+    of 264 bytes per point): the feature search then builds its fp16 operands from the fp32 rows while it stages them."""
 
     def __init__(self, normals, fpfh, fpfh_split, fpfh_norm, grad, bbox, voxel_size, grad_radius):
         self.normals, self.fpfh, self.grad, self.bbox = normals, fpfh, grad, bbox
@@ -158,25 +159,31 @@ class InstanceFeatures:
         self.voxel_size, self.grad_radius = float(voxel_size), float(grad_radius)
 
     def as_struct(self):
-        return _FeatStruct(self.normals.data_ptr(), self.fpfh.data_ptr(), self.fpfh_split.data_ptr(), self.fpfh_norm.data_ptr(),
+        return _FeatStruct(self.normals.data_ptr(), self.fpfh.data_ptr(), self.fpfh_split.data_ptr() if self.fpfh_split is not None else None,
+                           self.fpfh_norm.data_ptr(),
                            self.grad.data_ptr() if self.grad is not None else None,
                            self.bbox.ctypes.data, self.voxel_size, self.grad_radius)
 
 
-def instance_features_batch(ctx: RegContext, batch: CloudBatch, voxel_size: float, grad_radius: float = 0.0) -> InstanceFeatures:
+def instance_features_batch(ctx: RegContext, batch: CloudBatch, voxel_size: float, grad_radius: float = 0.0,
+                            compact: bool = False) -> InstanceFeatures:
     """Normals (2 voxel, 30 nn), FPFH (5 voxel, 100 nn) and, with grad_radius > 0, colour gradients (grad_radius, 30 nn) of
-    every cloud on its own, in the frame it is stored in -- what ibl_register_batch_cached reuses across jobs."""
+    every cloud on its own, in the frame it is stored in -- what ibl_register_batch_cached reuses across jobs.
+    compact: do not keep the rows a second time as fp16 search operands (96 of the 264 bytes per point; same registration results,
+    the matrix-core search converts on the fly -- for memories whose resident features would not fit otherwise)."""
     dev = batch.pts4.device
     n = max(batch.n, 1)
     normals = torch.empty((n, 4), dtype=torch.float32, device=dev)
     fpfh = torch.empty((n, 33), dtype=torch.float32, device=dev)
-    fpfh_split = torch.empty((n, 48), dtype=torch.float16, device=dev)      # the rows once more as fp16 search operands (csrc/reg_featnn.hip)
+    # the rows once more as fp16 search operands (csrc/reg_featnn.hip)
+    fpfh_split = None if compact else torch.empty((n, 48), dtype=torch.float16, device=dev)
     fpfh_norm = torch.empty((n,), dtype=torch.float32, device=dev)
     grad = torch.empty((n, 4), dtype=torch.float32, device=dev) if grad_radius > 0 else None
     bbox = np.zeros((max(batch.n_seg, 1), 6), dtype=np.float32)
     st = _lib.lib.ibl_instance_features_batch(ctx.handle, batch.pts4.data_ptr(), batch.seg_off.data_ptr(), batch.seg_off_host.ctypes.data,
                                               batch.n_seg, float(voxel_size), float(grad_radius), normals.data_ptr(), fpfh.data_ptr(),
-                                              fpfh_split.data_ptr(), fpfh_norm.data_ptr(), grad.data_ptr() if grad is not None else None, bbox.ctypes.data, _stream())
+                                              fpfh_split.data_ptr() if fpfh_split is not None else None, fpfh_norm.data_ptr(),
+                                              grad.data_ptr() if grad is not None else None, bbox.ctypes.data, _stream())
     _lib.check(st, "ibl_instance_features_batch")
     return InstanceFeatures(normals, fpfh, fpfh_split, fpfh_norm, grad, bbox, voxel_size, grad_radius)
 

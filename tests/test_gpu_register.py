@@ -76,7 +76,7 @@ def test_register_batch_vs_oracle(ctx, scene):
             G = out["T"][j].copy()
             G[:3, 3] = G[:3, 3] + mm - G[:3, :3] @ dm
             assert np.linalg.norm(G[:3, 3] - f["pose"][:3, 3]) < 0.05 and rot_deg(G, f["pose"]) < 1.5
-    assert n_same_ransac >= 4
+    assert n_same_ransac == len(assns)          # (hypothesis i of job j is a pure function of (seed, job id, i): the walks coincide)
 
 
 def test_point_to_point_fallback(ctx, scene):
@@ -232,7 +232,12 @@ def test_matrix_core_feature_search_equals_valu_search(ctx):
         finally:
             for k in env:
                 os.environ.pop(k, None)
+    # compact memory features (no resident fp16 operand rows: the search builds them from the fp32 rows as it stages them) -- the same
+    # bits in the operands, so the same candidates and the same results
+    fc = instance_features_batch(ctx, mem, 0.05, grad_radius=0.15, compact=True)
+    assert fc.fpfh_split is None and torch.equal(fc.fpfh[:mem.n], fm.fpfh[:mem.n]) and torch.equal(fc.fpfh_norm[:mem.n], fm.fpfh_norm[:mem.n])
+    outs.append(register_batch(ctx, det, mem, js, jt, 0.05, 1.5, 1.5, seed=3, job_id_base=40, det_features=fd, mem_features=fc))
     for k in ("T", "rmse", "fitness", "T_ransac", "ransac_stats"):
-        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]), k
+        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]) and np.array_equal(outs[0][k], outs[3][k]), k
     # the self-registration converges to the identity
     assert np.allclose(outs[0]["T"][4], np.eye(4), atol=1e-6) and outs[0]["fitness"][4] > 0.999

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times stage B of one bench step (outlier removal, detection features, register, evaluate) on synthetic frames, without the encoder:
 the detections' embeddings come from the generator.  IBL_TIMING=1 prints the host-synchronised phases of ibl_register_batch_cached;
-IBLOC_LIB=path selects a lab build.  usage: perf_register.py [frames] [memory]"""
+IBLOC_LIB=path selects a lab build; IBL_COMPACT=1 keeps the memory's instance features without their fp16 operand rows.  usage: perf_register.py [frames] [memory]"""
 import os
 import sys
 import time
@@ -20,7 +20,7 @@ def main():
     M = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     w = SynthWorld(M, pts_per_object=5000, E=4, D=64, seed=21)
     ctx = RegContext(16 << 30)
-    eng = LocaliseEngine(MemoryShard(ctx, list(w.embeddings), w.points, colors=w.colors))
+    eng = LocaliseEngine(MemoryShard(ctx, list(w.embeddings), w.points, colors=w.colors, compact_features=bool(int(os.environ.get("IBL_COMPACT", "0")))))
     rng = np.random.default_rng(5)
     batches = []
     for _ in range(4):
