@@ -386,7 +386,7 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
  *   3 * rank(c) + {b=1: 0, b=2: 1, b=0: 2}, rank over c = 5,4,6,3,7,2,8,1,9,0,10: the three histograms from their centre
  *   bins outwards, interleaved -- the order in which the feature search sums its squared differences, so that its
  *   early-abandon chain reads contiguously), fpfh_split / fpfh_norm [dev]: every row once more, CENTRED (x = row - a constant table, FM_MU of
- *   csrc/reg_api.hip), as 48 fp16 search operands
+ *   csrc/reg_common.h), as 48 fp16 search operands
  *   [x_0 .. x_32 | 8 8 | |x|^2 / 8 as hi + lo | 1e-3 |x|^2 + 4e-3 rounded up | 0 ..] and its squared norm -- the operands of the
  *   matrix-core filter of the feature search, whose one MFMA chain yields the whole distance bound (csrc/reg_featnn.hip), grad4 [dev] N x float4 or NULL (grad_radius <= 0: targets'
  *   gradients are recomputed per job), bbox [HOST] n_seg x 6 = (min xyz, max xyz) -- all written by
@@ -395,7 +395,8 @@ int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* d
 typedef struct {
     const float* normals4;
     const float* fpfh;
-    const uint16_t* fpfh_split;   /* [dev] N x 48 fp16 search operands (layout above) */
+    const uint16_t* fpfh_split;   /* [dev] N x 48 fp16 search operands (layout above), or NULL: COMPACT features (168 instead of 264
+                                   * bytes per point) -- the search builds the same operands from fpfh / fpfh_norm as it stages them */
     const float* fpfh_norm;       /* [dev] N: |centred row|^2 */
     const float* grad4;
     const float* bbox;

@@ -137,7 +137,7 @@ def normals_fpfh_batch(ctx: RegContext, batch: CloudBatch, radius_normal, max_nn
 # "matching order" of the 33 FPFH bins (histogram centres outwards, interleaved): instance features store their rows in this
 # order, the feature search sums its squared differences in it (csrc/reg_knn.hip FEAT_POS, oracle/oracle_reg.c FEAT_ORDER)
 FEAT_ORDER = np.array([b * 11 + c for c in (5, 4, 6, 3, 7, 2, 8, 1, 9, 0, 10) for b in (1, 2, 0)], dtype=np.int64)
-# the constant the fp16 search operands are centred by (csrc/reg_api.hip FM_MU; matching order)
+# the constant the fp16 search operands are centred by (csrc/reg_common.h FM_MU; matching order)
 FEAT_MU = np.array([87, 46, 101, 26, 28, 17, 26, 26, 17, 14, 21, 7, 14, 19, 7, 8, 14, 6, 8, 13, 6, 5, 11, 6, 5, 10, 6, 3, 7, 14, 3, 6, 14],
                    dtype=np.float32)
 
