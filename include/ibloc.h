@@ -300,7 +300,9 @@ int ibl_reg_ctx_destroy(ibl_reg_ctx* ctx);
 int ibl_reg_ctx_reset(ibl_reg_ctx* ctx);
 int64_t ibl_reg_ctx_high_water(const ibl_reg_ctx* ctx);
 /* device status word (bit 0: grid table overflow, bit 1: a k-NN query took the re-scan slow path; bits 2-3 are internal to
- * ibl_register_batch_cached); synchronises the device */
+ * ibl_register_batch_cached; bits 4 / 5, informational: a registration call since the last clear was redone with the VALU feature
+ * search / with a full-size RANSAC survivor list after the fast path's list overflowed -- same results, more time); synchronises the
+ * device */
 int ibl_reg_ctx_status(ibl_reg_ctx* ctx, int clear);
 
 /* Clouds are passed as batches of segments: pts4 [dev] N x float4 (x, y, z, intensity =

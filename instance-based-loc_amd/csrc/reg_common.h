@@ -90,7 +90,9 @@ static inline T* arena_alloc(ibl_reg_ctx* ctx, int64_t count, bool* ok) {
 #define IBL_ST_GRID_OVERFLOW 1
 #define IBL_ST_KNN_SLOWPATH 2
 #define IBL_ST_FEAT_OVERFLOW 4       // the matrix-core feature search overflowed its candidate list: the call is redone with the VALU search
-#define IBL_ST_RANSAC_OVERFLOW 8     // more surviving hypotheses in a round than the list holds (ibl_register_batch returns an error)
+#define IBL_ST_RANSAC_OVERFLOW 8     // more surviving hypotheses in a round than the list holds: the call is redone with a full-size list
+#define IBL_ST_FEAT_REDONE 16        // (sticky, informational) a registration call was redone with the VALU feature search
+#define IBL_ST_RANSAC_REDONE 32      // (sticky, informational) a registration call was redone with a full-size survivor list
 
 // grid construction (reg_grid.hip)
 int ibl_build_batch_grid(ibl_reg_ctx* ctx, const float4* pts, const int* seg_off_dev, const int* seg_off_host, int n_seg,

@@ -1173,6 +1173,7 @@ static thread_local bool tl_ransac_full_list = false;   // set while a call is r
 static thread_local const uint32_t* tl_job_ids = nullptr;   // ibl_register_batch_ids: the caller's job ids for the duration of its call
 
 __global__ void ibl_status_clear_kernel(int* __restrict__ status, int mask) { atomicAnd(status, ~mask); }
+__global__ void ibl_status_set_kernel(int* __restrict__ status, int mask) { atomicOr(status, mask); }
 extern "C" int ibl_register_batch(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
                                   int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
                                   int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs, double voxel_size,
@@ -1884,6 +1885,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         // pass are unusable -- once more with a list that holds every hypothesis of a round (same hypotheses, same fold order: same result
         // as a pass whose list never overflowed)
         tl_ransac_full_list = true;
+        hipLaunchKernelGGL(ibl_status_set_kernel, dim3(1), dim3(1), 0, s, ctx->d_status, IBL_ST_RANSAC_REDONE);
         const int st2 = ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
                                                   job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed,
                                                   job_id_base, ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out,
@@ -1897,6 +1899,7 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         // the candidate list of the matrix-core feature search overflowed (results of this pass are unusable): once more with the VALU
         // search, which has no list
         tl_force_valu = true;
+        hipLaunchKernelGGL(ibl_status_set_kernel, dim3(1), dim3(1), 0, s, ctx->d_status, IBL_ST_FEAT_REDONE);
         const int st2 = ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
                                                   job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed,
                                                   job_id_base, ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out,

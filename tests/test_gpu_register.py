@@ -241,3 +241,27 @@ def test_matrix_core_feature_search_equals_valu_search(ctx):
         assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]) and np.array_equal(outs[0][k], outs[3][k]), k
     # the self-registration converges to the identity
     assert np.allclose(outs[0]["T"][4], np.eye(4), atol=1e-6) and outs[0]["fitness"][4] > 0.999
+
+
+def test_ransac_survivor_list_overflow_is_redone_with_a_full_list(ctx):
+    """a round in which more hypotheses pass the edge-length test than the survivor list holds (sized for ~6 % of a round)
+    used to fail the whole batch.  Clouds registered onto exact copies of themselves: every correspondence is right, so every
+    hypothesis survives; a fixed budget keeps all four jobs running into the 262 144-hypothesis round, whose 1 M survivors exceed the
+    list.  The call must redo itself with a full-size list (status bit 5) and return what the same jobs give one at a time (a single
+    job's rounds fit the list)."""
+    from ibloc_amd.registration import CloudBatch, register_batch
+    w = SynthWorld(4, pts_per_object=1500, E=1, D=8, seed=17, spacing=3.0)
+    ints = [ro.intensity(c) for c in w.colors]
+    det = CloudBatch.from_numpy(w.points, ints)
+    mem = CloudBatch.from_numpy(w.points, ints)
+    js = [[j, -1, -1] for j in range(4)]
+    kw = dict(seed=5, ransac_max_iter=300000, fixed_budget=True)
+    ctx.status()                                                          # clear
+    out = register_batch(ctx, det, mem, js, js, 0.05, 1.5, 1.5, job_ids=np.arange(4, dtype=np.uint32) + 7, **kw)
+    assert ctx.status() & 32, "the survivor list did not overflow: the case no longer exercises the redo"
+    for j in range(4):
+        one = register_batch(ctx, det, mem, [js[j]], [js[j]], 0.05, 1.5, 1.5, job_ids=np.array([7 + j], dtype=np.uint32), **kw)
+        assert ctx.status() & 32 == 0
+        for k in ("T", "rmse", "fitness", "T_ransac", "ransac_stats"):
+            assert np.array_equal(out[k][j], one[k][0]), (j, k)
+        assert np.allclose(out["T"][j], np.eye(4), atol=1e-6) and out["fitness"][j] > 0.999
