@@ -224,20 +224,18 @@ int ibl_build_batch_grid_bounded(ibl_reg_ctx* ctx, const float4* pts, const int*
     return grid_fill(ctx, pts, seg_off_dev, n_seg, n, seg, (int)cells_bound, out, s);
 }
 
-// Defaults from a sweep on the detections of a bench step (tools/lab_knn_grid.sh, 1.04 M points in 210 clouds, ms per feature call;
-// the results do not depend on the knobs -- a tile proves its queries or hands them to the grid walk):
-//   rho \ safety   0.6    0.8    1.0    1.25   1.6        fallback at 0.8 / 1.0
-//   2              9.05   8.53   8.92   9.08   9.61       1.4 % / 0.5 %
-//   3             10.85   9.00   9.05   9.08   9.16       2.0 % / 0.4 %        (3 / 1.0: rounds 2-3)
-//   4             13.88  10.46   9.64   9.58   9.78       2.4 % / 0.5 %
-// A reach of two larger cells stages about the same cube as three smaller ones, but a tile of 2^3 cells then holds 21 instead of 9
-// queries: the per-tile set-up is shared by more of them.
+// Defaults from sweeps on the detections of a bench step (tools/lab_knn_grid.sh, 1.04 M points in 210 clouds, ms per feature call;
+// the results do not depend on the knobs -- a tile proves its queries or hands them to the grid walk).  With the 100-neighbour search
+// on 1 600-candidate packed tiles, three workgroups per CU (reg_knn.hip):
+//   rho 2: safety 0.6 7.64 | 0.7 7.41 | 0.8 7.44 | 1.0 7.80 (9.7 % of the queries overflow their cube)
+//   rho 3: safety 0.7 7.89 | 0.8 7.33 | 0.9 7.16 | 1.0 7.14 | 1.1 7.02 | 1.25 7.06 | 1.5 7.30      rho 4: 1.25 7.43
+// (on the 2 560-candidate tiles, two workgroups per CU, the best was rho 2 / 0.8: 8.53 against 9.05 at 3 / 1.0.)
 double ibl_knn_safety() {
-    static const double v = [] { const char* e = getenv("IBL_KNN_SAFETY"); return e ? atof(e) : 0.8; }();
+    static const double v = [] { const char* e = getenv("IBL_KNN_SAFETY"); return e ? atof(e) : 1.1; }();
     return v;
 }
 int ibl_knn_rho() {
-    static const int v = [] { const char* e = getenv("IBL_KNN_RHO"); const int r = e ? atoi(e) : 2; return r < 1 ? 1 : (r > 4 ? 4 : r); }();
+    static const int v = [] { const char* e = getenv("IBL_KNN_RHO"); const int r = e ? atoi(e) : 3; return r < 1 ? 1 : (r > 4 ? 4 : r); }();
     return v;
 }
 

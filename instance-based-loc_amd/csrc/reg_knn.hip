@@ -27,6 +27,9 @@
 #define KNN_ROWS 8        // candidate rows whose first 64 points are in flight together
 #endif
 #define KNN_CAPB 256
+#ifndef KNN_TILE_CAP3
+#define KNN_TILE_CAP3 1600     // candidates of a packed tile: 3 x (1 600 x 16 B + tables + 4 x 6.5 KB of wave scratch) fit a CU's 160 KB
+#endif
 #ifndef KNN_GUESS_SHIFT
 #define KNN_GUESS_SHIFT 2      // margin of the threshold-bin guess: + 1 / 4 (12.5 % and 50 % measured 1 % slower)
 #endif
@@ -109,6 +112,7 @@ struct TileLds {
     int row_off[KT_ROWS + 1];
     int q_b[16];
     int q_off[17];
+    int next_q;              // the next query of the tile nobody has taken yet (tile_knn_block: waves take queries as they finish)
     __device__ __forceinline__ int ord_of(int t) const { return PACK ? __float_as_int(pts[t].w) : ord[t]; }
 };
 
@@ -1372,6 +1376,7 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
         int acc = 0;
         T.q_off[0] = 0;
         for (int r = 0; r < qrows; ++r) { acc += T.q_off[r + 1]; T.q_off[r + 1] = acc; }
+        T.next_q = NW;
     }
     __syncthreads();
     const int nq = T.q_off[qrows];
@@ -1502,7 +1507,14 @@ __device__ void tile_knn_block(const BatchGrid& g, float radius, float r2, int m
 #endif
     int run_r = 0;
     const int sny = y1 - y0 + 1;
-    for (int qk = wave; qk < nq; qk += NW) {
+    // A wave's first query is its own number; after that it takes the next one nobody has taken (queries differ in cost -- list or
+    // two-pass selection, candidates in reach -- and a tile ends with its slowest wave: taking them in turn left the others idle)
+    auto next_query = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&T.next_q, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    for (int qk = wave; qk < nq; qk = next_query()) {
         while (qk >= T.q_off[run_r + 1]) ++run_r;
         const int jq = T.q_b[run_r] + (qk - T.q_off[run_r]);
         // a query is a point of the tile, and the tile lies inside its staged cube: the point and its original index come from LDS (the two
@@ -1554,7 +1566,7 @@ struct NormalFactory {
     template <class Acc> __device__ void flush_block(Pending* pend, const Acc& acc) const { normal_flush_block(pend, acc, normals); }
 };
 struct SpfhFactory {
-    static constexpr bool WIDE = true;       // six waves per workgroup + packed tile for the 100-neighbour search (geometry only)
+    static constexpr bool WIDE = true;       // geometry only: the packed tile (original index in the staged point's w)
     typedef NoPending Pending;
     const float4* normals; unsigned char* spfh_cnt; int* nbr_idx; float* nbr_d2; int* nbr_cnt; int K;
     template <class Acc> __device__ void flush(Pending*, const Acc&) const {}
@@ -1593,12 +1605,16 @@ struct GradFactory {
 };
 
 // tiles: one workgroup each.  NW waves per workgroup; PACK: original indices in the staged points' w (see TileLds)
-template <int TS, int CAP, class Factory, int NW = 4, bool PACK = false>
-__global__ __launch_bounds__(NW * 64) void ibl_knn_tile_kernel(BatchGrid g, float radius, float r2, int max_nn, NeedPop need_pop, Factory fac,
+template <int TS, int CAP, class Factory, int NW = 4, bool PACK = false, int OCC = 1>
+__global__ __launch_bounds__(NW * 64, OCC) void ibl_knn_tile_kernel(BatchGrid g, float radius, float r2, int max_nn, NeedPop need_pop, Factory fac,
                                                               int q_lo, int q_hi, int* __restrict__ fb_list, int* __restrict__ fb_count) {
     __shared__ TileLds<CAP, PACK> T;
     __shared__ WaveLds wl[NW];
     __shared__ typename Factory::Pending pend[NW];
+#ifdef KNN_LAB_PAD_LDS       // lab: pad the workgroup's LDS so that only one fits a CU (is the kernel bound by resident waves?)
+    __shared__ int lab_pad[KNN_LAB_PAD_LDS / 4];
+    if (threadIdx.x == 0 && q_lo == -12345) lab_pad[max_nn] = 1;
+#endif
     tile_knn_block<TS, NW>(g, radius, r2, max_nn, need_pop, fb_list, fb_count, fac, q_lo, q_hi, T, wl, pend);
 }
 
@@ -1768,16 +1784,23 @@ static int launch_knn(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, c
         IBL_ARENA(fb_count, int, 64);
         IBL_HIP_CHECK(hipMemsetAsync(fb_count, 0, sizeof(int), s));
         const NeedPop np = need_pop_table(max_nn, g.ts);
-        // LDS budget of the staged cube: 20 B per candidate.  The 100-neighbour search (tiles of 2^3 cells) stages up to 2 560 points
-        // (77 KiB per workgroup with the four waves' selection scratch: two workgroups per CU), the 30-neighbour ones 1 024
-        // Measured and rejected (round 3): six waves per workgroup on a packed tile (original index in the staged point's w: 2 528 candidates
-        // x 16 B + six waves' scratch = 81.7 KB, 129 VGPRs: two workgroups = TWELVE waves per CU instead of eight) ran the 100-neighbour
-        // search in 7.13 ms against 5.27 ms -- more resident waves do not help this kernel, the per-tile set-up and barriers are then
-        // shared by 3.5 instead of 5.3 queries per wave.  -DIBL_KNN_WIDE builds that form.
-#ifdef IBL_KNN_WIDE
-        if (g.ts == 2 && Factory::WIDE) hipLaunchKernelGGL((ibl_knn_tile_kernel<2, 2528, Factory, 6, true>), dim3(g.n_tiles), dim3(384), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
+        // LDS budget of the staged cube.  The kernel is bound by its resident workgroups: padded to ONE workgroup per CU it ran the
+        // 100-neighbour search in 10.6 ms against 5.4 ms with two (lab: -DKNN_LAB_PAD_LDS).  Round 3, final form for the consumers that read
+        // geometry only (Factory::WIDE): a PACKED tile (the original index rides in the staged point's w: 16 instead of 20 B per candidate)
+        // of 1 600 candidates + the four waves' scratch = 53.5 KB and a 168-register launch bound -> THREE four-wave workgroups per CU:
+        // feature call 8.49 -> 7.0 ms although 0.4 % (not 0.1 %) of the queries now overflow a cube and join the grid walk.  (Six waves per
+        // workgroup on a 2 528-candidate packed tile -- also twelve waves per CU -- was slower, 7.13 vs 5.27 ms for the search: the
+        // per-tile set-up and barriers are then shared by fewer queries per wave.)  The colour-gradient
+        // search reads the staged intensity and keeps the 20-byte tile (1 024 candidates, three workgroups per CU as well).
+        bool packed = false;
+        if constexpr (Factory::WIDE) {
+            if (g.ts == 2) {
+                packed = true;
+                hipLaunchKernelGGL((ibl_knn_tile_kernel<2, KNN_TILE_CAP3, Factory, 4, true, 3>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
+            }
+        }
+        if (packed) {}
         else
-#endif
         if (g.ts == 2) hipLaunchKernelGGL((ibl_knn_tile_kernel<2, 2560, Factory>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
         else if (g.ts == 4) hipLaunchKernelGGL((ibl_knn_tile_kernel<4, 1024, Factory>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
         else return ibl_set_error(IBL_ERR_INTERNAL, "k-NN tiles of %d^3 cells are not built", g.ts);
