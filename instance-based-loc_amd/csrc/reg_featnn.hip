@@ -75,7 +75,12 @@ __device__ __forceinline__ void fm_split_norm(float v, _Float16* h, _Float16* l)
 // bytes per point): its pieces are built from the fp32 rows (fm_operand_piece: the same bits ibl_fpfh_half_kernel would have stored) --
 // the queries' once per wave, the database's as a chunk is stashed (the raw floats wait in registers where the stored piece would).
 template <int PASS, bool INDEXED, bool CONV>
-__global__ __launch_bounds__(256, 2) void ibl_feat_mfma_kernel(const FeatPair* __restrict__ pairs, FeatSources src, float* __restrict__ up,
+// pass 2 waits on its hit path (PMC: 63 % of its wave time): five instead of four waves per SIMD (a 96-register bound; three dwords
+// spill outside the chunk loop) 2.05 -> 1.91 ms; six (80 registers) spills into the loop, 2x slower
+#ifndef FM_OCC2
+#define FM_OCC2 5
+#endif
+__global__ __launch_bounds__(256, PASS == 2 ? FM_OCC2 : 2) void ibl_feat_mfma_kernel(const FeatPair* __restrict__ pairs, FeatSources src, float* __restrict__ up,
                                                             FmCand* __restrict__ cand, unsigned long long* __restrict__ n_cand, int cand_cap,
                                                             const int* __restrict__ need_pos, const int* __restrict__ need_list, int out0, int cstride) {
     const FeatPair P = pairs[blockIdx.y];
