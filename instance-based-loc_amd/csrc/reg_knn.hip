@@ -1796,7 +1796,11 @@ static int launch_knn(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, c
         if constexpr (Factory::WIDE) {
             if (g.ts == 2) {
                 packed = true;
+#ifdef KNN_LAB_NW          // lab: KNN_LAB_NW waves per workgroup, KNN_LAB_OCC workgroups per CU
+                hipLaunchKernelGGL((ibl_knn_tile_kernel<2, KNN_TILE_CAP3, Factory, KNN_LAB_NW, true, KNN_LAB_OCC>), dim3(g.n_tiles), dim3(64 * KNN_LAB_NW), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
+#else
                 hipLaunchKernelGGL((ibl_knn_tile_kernel<2, KNN_TILE_CAP3, Factory, 4, true, 3>), dim3(g.n_tiles), dim3(256), 0, s, g, r, r2, max_nn, np, fac, q0, q1, fb_list, fb_count);
+#endif
             }
         }
         if (packed) {}
