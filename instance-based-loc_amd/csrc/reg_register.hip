@@ -547,8 +547,17 @@ __device__ inline bool ransac_hypothesis(long long i, unsigned job_id, unsigned 
 // check, ~99 % rejected) runs on every lane; the survivors of the whole chunk are compacted through LDS so that the
 // expensive part (fp64 Kabsch + distance check) runs once, on densely packed lanes.  `flags` is zeroed by the host before the launch.
 constexpr int RANSAC_LDS_CORR = 1024;    // correspondences staged in LDS (32 KiB)
+// Blocks of the well-filled rounds (run_round): 8 k hypotheses.  16 k amortise the dense Kabsch pass over more survivors, but their 32 KB
+// survivor table + the 32 KB of staged correspondences leave two workgroups per CU; 8 k blocks (48 KB, registers bound to 168) run three:
+// 653 -> 554 us for the 262 144-hypothesis round of a bench step.
+#ifndef RANSAC_BIG_SUBS
+#define RANSAC_BIG_SUBS 8
+#endif
+#ifndef RANSAC_BIG_OCC
+#define RANSAC_BIG_OCC 3                 // its workgroups per CU the registers must allow
+#endif
 template <int RANSAC_SUBS>               // 1024-hypothesis passes per block (one Kabsch pass over all their survivors)
-__global__ __launch_bounds__(256) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
+__global__ __launch_bounds__(256, RANSAC_SUBS == RANSAC_BIG_SUBS ? RANSAC_BIG_OCC : 1) void ibl_ransac_flag_kernel(const RansacState* __restrict__ st, const float4* __restrict__ cp,
                                                               const int* __restrict__ job_off, const int* __restrict__ n_corr,
                                                               long long max_iter, double max_dist, double edge_sim, unsigned seed_lo,
                                                               unsigned seed_hi, unsigned job_id_base, int round_size,
@@ -1751,11 +1760,12 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
                 const int nblk = round_size / 256;
                 const int n_tab = n_act * nblk;           // tables are indexed by (slot in the active list, block)
                 IBL_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_act * round_size, s));
-                // 16 k-hypothesis blocks amortise the dense Kabsch pass best, but a round of few jobs (or the 32 k round of all of them) is a few
-                // hundred such blocks -- under two per CU, each ~120 us long: those rounds run as 4 k blocks (same flags: a hypothesis does not
+                // large blocks amortise the dense Kabsch pass best, but a round of few jobs (or the 32 k round of all of them) is a few
+                // hundred of them -- under two per CU, each ~120 us long: those rounds run as 4 k blocks (same flags: a hypothesis does not
                 // know its block)
-                if (round_size >= 16384 && (int64_t)(round_size / 16384) * n_act >= RANSAC_WIDE_MIN_BLOCKS)
-                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<16>, dim3(round_size / 16384, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
+                constexpr int BIG = 1024 * RANSAC_BIG_SUBS;
+                if (round_size >= BIG && (int64_t)(round_size / 16384) * n_act >= RANSAC_WIDE_MIN_BLOCKS)
+                    hipLaunchKernelGGL(ibl_ransac_flag_kernel<RANSAC_BIG_SUBS>, dim3(round_size / BIG, n_act), dim3(256), 0, s, rs, cp, d_job_off, n_corr,
                                        (long long)ransac_max_iter, max_dist, 0.9, (unsigned)seed, (unsigned)(seed >> 32), job_id_base, round_size, flags,
                                        blk_cnt, active);
                 else
