@@ -767,6 +767,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
     constexpr int VROW = KEYS * 2 + 16;     // bytes per V^T row
     __shared__ __attribute__((aligned(16))) unsigned char sK[KEYS * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char sV[64 * VROW];
+#ifdef ATT_LAB_PAD_LDS       // lab: pad the LDS so that one workgroup fits a CU (is the kernel bound by its resident workgroups?)
+    __shared__ int lab_pad[ATT_LAB_PAD_LDS / 4];
+    if (threadIdx.x == 0 && T == -12345) lab_pad[D] = 1;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
