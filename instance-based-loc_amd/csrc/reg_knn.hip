@@ -1753,9 +1753,12 @@ __global__ __launch_bounds__(256) void ibl_radius_count_kernel(BatchGrid g, cons
         for (int y = max(cy - reach, 0); y <= min(cy + reach, sg.ny - 1) && cnt <= nb_points; ++y) {
             const int row = sg.cell_base + (z * sg.ny + y) * sg.nx;
             const int b = g.cell_start[row + max(cx - reach, 0)], e = g.cell_start[row + min(cx + reach, sg.nx - 1) + 1];
-            for (int j = b; j < e && cnt <= nb_points; ++j) {
-                const float4 p = g.sorted_pts[j];
-                cnt += dist2f(q.x, q.y, q.z, p.x, p.y, p.z) < r2 ? 1 : 0;
+            for (int j = b; j < e && cnt <= nb_points; j += 4) {         // four loads in flight (the walk is a chain of load latencies)
+                float4 p[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) p[v] = g.sorted_pts[min(j + v, e - 1)];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cnt += (j + v < e && dist2f(q.x, q.y, q.z, p[v].x, p[v].y, p[v].z) < r2) ? 1 : 0;
             }
         }
     keep[qi] = cnt > nb_points ? 1 : 0;
