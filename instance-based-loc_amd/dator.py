@@ -66,6 +66,70 @@ def fold_lora(w: dict) -> dict:
     return out
 
 
+_HEAD_NAMES = {"proj_local_rgb": "project_local_rgb", "proj_global_rgb": "project_global_rgb", "merge_rgb": "merge_local_global_rgb",
+               "proj_local_depth": "project_local_depth", "proj_global_depth": "project_global_depth",
+               "merge_depth": "merge_local_global_depth", "Q_r": "Q_r", "V_r": "V_r", "Q_d": "Q_d", "V_d": "V_d"}
+
+
+def fourdnet_state_dict_to_weights(state_dict: dict):
+    """A `build_FourDNet` checkpoint (what the reference's `load_model('.../dator_best_tum.pth')` reads,
+    utils/embeddings.py:101-103 -> build_FourDNet.load_param, dator/model/make_model.py:620-626) -> (rgb stream weights, depth stream
+    weights, head weights) in the dict layouts DatorEncoder takes.
+
+    Follows load_param: a `module.` prefix (DataParallel checkpoints) is stripped, `classifier*` entries are skipped.  `base.*` is the
+    RGB TransReID stream, `base2.*` the depth stream (make_model.py:459-463); their LoRA factors (`attn.qkv_lora_down_matrix` /
+    `_up_matrix`, blocks 10-11, vit_pytorch.py:176-177) stay separate entries here and are folded by DatorEncoder.  Parameters the
+    forward never reads are ignored: the streams' own `norm` / `fc` (local_feature=True returns before them, vit_pytorch.py:437-443)
+    and `sie_embed`.  A missing parameter raises KeyError naming the checkpoint key."""
+    sd = {}
+    for k, v in state_dict.items():
+        k = k.replace("module.", "")
+        if k.find("classifier") != -1:
+            continue
+        sd[k] = v
+
+    def g(k):
+        if k not in sd:
+            raise KeyError(f"DATOR checkpoint lacks '{k}'")
+        v = sd[k]
+        v = v.detach().float().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        return np.ascontiguousarray(v, dtype=np.float32)
+
+    def stream(prefix):
+        w = {"cls": g(prefix + "cls_token").reshape(-1), "pos": g(prefix + "pos_embed")[0],
+             "patch.w": g(prefix + "patch_embed.proj.weight"), "patch.b": g(prefix + "patch_embed.proj.bias")}
+        n_pos = 1 + STREAM_CFG.pos_grid[0] * STREAM_CFG.pos_grid[1]
+        if w["pos"].shape != (n_pos, STREAM_CFG.dim):
+            raise ValueError(f"{prefix}pos_embed has shape {w['pos'].shape}, the 256x128 / stride-16 stream expects {(n_pos, STREAM_CFG.dim)}")
+        dim = STREAM_CFG.dim
+        for l in range(STREAM_CFG.depth):
+            p, q = f"{prefix}blocks.{l}.", f"l{l}."
+            w[q + "ln1.g"], w[q + "ln1.b"] = g(p + "norm1.weight"), g(p + "norm1.bias")
+            w[q + "ln2.g"], w[q + "ln2.b"] = g(p + "norm2.weight"), g(p + "norm2.bias")
+            wq, bq = g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias")
+            for i, n in enumerate("qkv"):
+                w[q + n + ".w"], w[q + n + ".b"] = wq[i * dim:(i + 1) * dim].copy(), bq[i * dim:(i + 1) * dim].copy()
+            w[q + "o.w"], w[q + "o.b"] = g(p + "attn.proj.weight"), g(p + "attn.proj.bias")
+            w[q + "fc1.w"], w[q + "fc1.b"] = g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias")
+            w[q + "fc2.w"], w[q + "fc2.b"] = g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias")
+            if p + "attn.qkv_lora_down_matrix" in sd:
+                w[q + "lora_down"], w[q + "lora_up"] = g(p + "attn.qkv_lora_down_matrix"), g(p + "attn.qkv_lora_up_matrix")
+        # VitEncoder reads a final-LayerNorm entry only when cfg.final_ln; the streams run without it
+        return w
+
+    hw = {}
+    for mine, ref in _HEAD_NAMES.items():
+        hw[mine + ".w"], hw[mine + ".b"] = g(ref + ".weight"), g(ref + ".bias")
+    for op in ATTN_OPS:
+        hw[op + ".sel.w"], hw[op + ".sel.b"] = g(f"{op}_selector.0.weight"), g(f"{op}_selector.0.bias")
+        hw[op + ".aw.w"], hw[op + ".aw.b"] = g(f"{op}_attn_weights.0.weight"), g(f"{op}_attn_weights.0.bias")
+        hw[op + ".ffn.w"], hw[op + ".ffn.b"] = g(f"{op}_ffn.weight"), g(f"{op}_ffn.bias")
+        hw[op + ".norm.g"], hw[op + ".norm.b"] = g(f"{op}_norm.weight"), g(f"{op}_norm.bias")
+    for i in range(4):
+        hw[f"hyper.{i}.w"], hw[f"hyper.{i}.b"] = g(f"hypernet.{2 * i}.weight"), g(f"hypernet.{2 * i}.bias")
+    return stream("base."), stream("base2."), hw
+
+
 class DatorHeadWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ["proj_local_rgb_w", "proj_local_rgb_b", "proj_global_rgb_w", "proj_global_rgb_b", "merge_rgb_w", "merge_rgb_b",

@@ -3,7 +3,7 @@
 The reference loads four encoders at import time by fetching checkpoints by name
 (/root/reference/utils/embeddings.py:13-28, 101-103) and embeds ONE crop per call.  Here the encoders are
 `ibloc_amd.vit.VitEncoder` objects (HIP kernels behind the C-ABI) registered once with `set_encoder(kind, encoder)`
-or built from a converted checkpoint with `load_encoder(kind, state_dict)`; the four reference entry points keep
+or built from a converted checkpoint with `load_encoder(kind, state_dict)` (kinds "dino" | "vit" | "clip" | "dator"); the four reference entry points keep
 their names and `(**kwargs) -> torch.Tensor` signature:
 
     get_all_clip_embeddings   :31-50   L2-normalised 512-d
@@ -93,9 +93,22 @@ def open_clip_visual_to_weights(sd: dict, depth: int) -> dict:
     return w
 
 
-def load_encoder(kind: str, state_dict: dict, device="cuda", cfg: V.VitConfig = None) -> V.VitEncoder:
-    """Build + register the encoder of `kind` ("dino" | "vit" | "clip") from a checkpoint state dict.  cfg: another architecture /
-    position-embedding rule than the checkpoint the reference loads (default: V.CONFIGS of the kind)."""
+def load_encoder(kind: str, state_dict, device="cuda", cfg: V.VitConfig = None):
+    """Build + register the encoder of `kind` ("dino" | "vit" | "clip" | "dator") from a checkpoint state dict.  cfg: another
+    architecture / position-embedding rule than the checkpoint the reference loads (default: V.CONFIGS of the kind).
+
+    "dator": `state_dict` is a `build_FourDNet` checkpoint as the reference's `load_model('.../dator_best_tum.pth')` reads it
+    (utils/embeddings.py:101-103, make_model.py:620-626) -- the dict itself or the path of the `.pth` file (loaded with
+    `weights_only=True`: a checkpoint is data) -> `ibloc_amd.dator.DatorEncoder` (`module.` prefix stripped, `classifier*` skipped, LoRA
+    folded into the QKV weights)."""
+    if kind == "dator":
+        from ibloc_amd import dator as D
+        if isinstance(state_dict, (str, bytes)) or hasattr(state_dict, "__fspath__"):
+            state_dict = torch.load(state_dict, map_location="cpu", weights_only=True)
+        rw, dw, hw = D.fourdnet_state_dict_to_weights(state_dict)
+        enc = D.DatorEncoder(rw, dw, hw, device=device)
+        set_encoder(kind, enc)
+        return enc
     cfg = cfg or V.CONFIGS[_KIND_TO_CONFIG[kind]]
     conv = {"dino": hf_dinov2_to_weights, "vit": hf_vit_to_weights, "clip": open_clip_visual_to_weights}[kind]
     enc = V.VitEncoder(cfg, conv(state_dict, cfg.depth), device=device)

@@ -146,3 +146,59 @@ def test_hf_444_position_embedding_rule():
     assert np.abs(got[1:] - want).max() < 2e-5
     other = V.interpolate_pos_embed(pos, dataclasses.replace(small, pos_interp="size"))
     assert np.abs(other[1:] - want).max() > 1e-3            # the size= rule is a different resampling
+
+
+def _fourdnet_checkpoint(rw, dw, hw, prefix="module."):
+    """A checkpoint with EXACTLY the entries of the reference model's own state_dict() (names and shapes recorded from the live
+    `build_FourDNet` in the build container: tests/golden/dator_state_keys.json, tools/gen_golden_dator.py), filled with the given weights
+    through the reference's parameter names; entries the forward never reads (classifier, the streams' norm / fc) get noise."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("gen_golden_dator", os.path.join(here, "..", "tools", "gen_golden_dator.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    keys = json.load(open(os.path.join(here, "golden", "dator_state_keys.json")))
+    sd = {}
+    gen.stream_state("base.", rw, sd)
+    gen.stream_state("base2.", dw, sd)
+    gen.head_state(hw, sd)
+    assert set(sd) <= set(keys), sorted(set(sd) - set(keys))[:5]
+    g = torch.Generator().manual_seed(11)
+    for k, shape in keys.items():
+        if k in sd:
+            assert list(sd[k].shape) == shape, (k, list(sd[k].shape), shape)
+        else:
+            assert any(a in k for a in ("classifier", ".fc.", ".norm.")), k          # what load_param copies but forward() never reads
+            sd[k] = torch.randn(shape, generator=g)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def test_fourdnet_checkpoint_converter():
+    """load_encoder("dator", ...)'s converter on a checkpoint shaped like the reference's dator_best_tum.pth (make_model.py:620-626):
+    `module.` prefix stripped, classifier skipped, LoRA factors kept for folding -- and the converted weights reproduce the embedding the
+    reference's own build_FourDNet computed from the same parameters (tests/golden/dator_golden.npz)."""
+    import os
+    from ibloc_amd import dator as D
+    from oracle import dator_oracle as do
+    rw, dw, hw = D.random_stream_weights(301), D.random_stream_weights(302), D.random_head_weights(303)
+    ck = _fourdnet_checkpoint(rw, dw, hw)
+    rw2, dw2, hw2 = D.fourdnet_state_dict_to_weights(ck)
+    for got, want in ((rw2, rw), (dw2, dw), (hw2, hw)):
+        assert set(want) - set(got) <= {"ln_f.g", "ln_f.b"} and set(got) <= set(want)
+        for k in got:
+            assert np.array_equal(got[k], np.asarray(want[k], dtype=np.float32).reshape(got[k].shape)), k
+    assert "l10.lora_down" in rw2 and "l11.lora_up" in dw2 and "l9.lora_down" not in rw2
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "dator_golden.npz"))
+    rng = np.random.default_rng(304)
+    rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
+    depth = np.repeat(rng.uniform(-1, 1, size=(3, 1, 256, 128)).astype(np.float32), 3, axis=1)
+    emb = do.forward(rw2, dw2, hw2, D.STREAM_CFG, rgb[:1], depth[:1])
+    assert np.abs(emb - gold["embedding"][:1]).max() < 2e-4 * max(1.0, np.abs(gold["embedding"]).max())
+    # no prefix (a plain checkpoint) reads the same; a truncated checkpoint names the missing entry
+    plain = {k[len("module."):]: v for k, v in ck.items()}
+    assert np.array_equal(D.fourdnet_state_dict_to_weights(plain)[2]["Q_r.w"], hw2["Q_r.w"])
+    del plain["base2.blocks.3.mlp.fc2.weight"]
+    with pytest.raises(KeyError, match="base2.blocks.3.mlp.fc2.weight"):
+        D.fourdnet_state_dict_to_weights(plain)

@@ -72,3 +72,23 @@ def test_preprocess_and_facade(enc):
     assert out.shape == (128,)
     exp1 = do.forward(rw, dw, hw, D.STREAM_CFG, do.preprocess_rgb(crops[0])[None], do.preprocess_depth(full_depth[30:150, 20:110])[None])[0]
     assert np.linalg.norm(out.cpu().numpy() - exp1) / np.linalg.norm(exp1) <= 3e-3
+
+
+def test_load_encoder_from_a_reference_shaped_checkpoint(tmp_path):
+    """utils.embeddings.load_encoder("dator", <checkpoint>) -- what replaces the reference's load_model('.../dator_best_tum.pth')
+    (utils/embeddings.py:101-103): a `.pth` file with the reference model's own entry names (`module.` prefix, classifier included)
+    goes through the converter into the HIP encoder, whose embedding matches the reference's build_FourDNet golden."""
+    from ibloc_amd import dator as D
+    from ibloc_amd.utils import embeddings as emb
+    from tests.test_converters import _fourdnet_checkpoint
+    rw, dw, hw = D.random_stream_weights(301), D.random_stream_weights(302), D.random_head_weights(303)
+    path = str(tmp_path / "dator_ckpt.pth")
+    torch.save(_fourdnet_checkpoint(rw, dw, hw), path)
+    e = emb.load_encoder("dator", path)
+    rng = np.random.default_rng(304)
+    rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
+    depth = np.repeat(rng.uniform(-1, 1, size=(3, 1, 256, 128)).astype(np.float32), 3, axis=1)
+    got = e.forward_pixels(torch.from_numpy(rgb), torch.from_numpy(depth)).cpu().numpy()
+    ref = GOLD["embedding"]
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 2.5e-3
+    assert emb._encoder("dator") is e

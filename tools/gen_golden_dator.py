@@ -17,6 +17,7 @@ from ibloc_amd import dator as D  # noqa: E402
 
 REF = "/root/reference/dator"
 OUT = os.path.join(ROOT, "tests", "golden", "dator_golden.npz")
+OUT_KEYS = os.path.join(ROOT, "tests", "golden", "dator_state_keys.json")
 
 
 def t(a):
@@ -107,6 +108,19 @@ def main():
     np.savez_compressed(OUT, embedding=emb.astype(np.float32), rgb_tokens_cls=rgb_tok[:, 0].astype(np.float32),
                         rgb_tokens_mean=rgb_tok.mean(1).astype(np.float32))
     print("wrote", OUT)
+    # the checkpoint layout the reference's load_param reads (make_model.py:620-626): names and shapes of the model's own
+    # state_dict() -- data for tests/test_converters.py -- and the round trip through the product's converter, checked here against
+    # the live reference model: state_dict() (as a DataParallel checkpoint would carry it: `module.` prefix) -> weights == what was loaded
+    import json
+    ref_sd = model.state_dict()
+    json.dump({k: list(v.shape) for k, v in ref_sd.items()}, open(OUT_KEYS, "w"), indent=0)
+    print("wrote", OUT_KEYS, len(ref_sd), "entries")
+    rw2, dw2, hw2 = D.fourdnet_state_dict_to_weights({"module." + k: v for k, v in ref_sd.items()})
+    for got, want in ((rw2, rw), (dw2, dw), (hw2, hw)):
+        assert set(want) - set(got) <= {"ln_f.g", "ln_f.b"} and set(got) <= set(want), set(got) ^ set(want)   # the streams run without their final norm
+        for k in got:
+            assert np.array_equal(got[k], np.asarray(want[k], dtype=np.float32).reshape(got[k].shape)), k
+    print("converter round trip against the reference model's state_dict: identical")
 
 
 if __name__ == "__main__":
