@@ -7,6 +7,7 @@ clouds of every candidate assignment, whole-memory evaluation, on one MI355X.  `
     T   DINOv2-B/14, M = 10 000 (default; the row the >= 200 frames/s target is judged on)
     C2  DINOv2-B/14, M = 1 000          (BASELINE configs[1])
     C3  DATOR RGB-D dual stream (256x128 RGB + depth crops), M = 5 000, D = 128   (configs[2])
+    C1  DINOv2-S/14 (D = 384), M = 20, Q = 4 crops of 64..400 px per frame (configs[0], the reference's CPU-runnable plumbing case)
     C4  embed + match + assign only against M = 50 000 instances (configs[3]; one GPU holds the whole embedding memory, or its
         1/N instance range with --shard-memory under torch.distributed)
 A "step" is one pass of the hot path (ObjectMemory.localise body, object_memory.py:911-1131) over one batch of --frames synthetic
@@ -39,6 +40,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
+    # BASELINE configs[0]: the reference's own CPU-runnable case (TUM fr1/desk scale: DINOv2 ViT-S/14, 20-object memory, SURVEY 8d row C1:
+    # Q = 4 crops per frame of sizes H, W ~ U{64..400} through the PIL-exact resize kernel, 5 000-point clouds)
+    "C1": dict(model="dinov2_vits14", memory=20, points=5000, register=True, q=4, var_crops=True),
     "T": dict(model="dinov2_vitb14", memory=10000, points=5000, register=True),
     "C2": dict(model="dinov2_vitb14", memory=1000, points=5000, register=True),
     "C3": dict(model="dator", memory=5000, points=5000, register=True),
@@ -105,6 +109,40 @@ class Crops:
         return (rgb, torch.from_numpy(d.astype(np.float32)).to(device))
 
 
+class VarCrops:
+    """Crops of varying size (H, W ~ U{64..400}): the instance's low-frequency pattern evaluated on the crop's own
+    pixel grid + noise, so that every size goes through the resize / centre-crop kernel (`ibl_preprocess_crops`) like a detector's
+    bounding-box crop does."""
+
+    def __init__(self, seed, lo=64, hi=400):
+        self.seed, self.lo, self.hi = seed, lo, hi
+        self._par = {}
+
+    def params(self, k):
+        if k not in self._par:
+            r = np.random.default_rng([self.seed, int(k)])
+            self._par[k] = (r.uniform(0.5, 6, size=(3, 4, 2)), r.uniform(0, 2 * np.pi, size=(3, 4)), r.uniform(0.3, 1.0, size=(3, 4)))
+        return self._par[k]
+
+    def make(self, k, r, size=None):
+        h, w = size if size is not None else (int(r.integers(self.lo, self.hi + 1)), int(r.integers(self.lo, self.hi + 1)))
+        f, ph, amp = self.params(k)
+        yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+        img = np.empty((h, w, 3), dtype=np.float32)
+        for c in range(3):
+            acc = sum(amp[c, i] * np.sin(2 * np.pi * (f[c, i, 0] * xx + f[c, i, 1] * yy) + ph[c, i]) for i in range(4))
+            img[:, :, c] = 0.5 + acc / (2 * amp[c].sum())
+        img += r.normal(0, 0.03, size=img.shape).astype(np.float32)
+        return np.clip(img * 255.0, 0, 255).astype(np.uint8)
+
+    def variants_host(self, ids, r):
+        return [self.make(k, r) for k in ids]
+
+    def variants(self, ids, r, device):
+        from ibloc_amd.vit import PackedCrops
+        return PackedCrops(self.variants_host(ids, r), device)
+
+
 def make_encoder(model, device):
     from ibloc_amd import vit as V
     if model == "dator":
@@ -114,27 +152,8 @@ def make_encoder(model, device):
     return V.VitEncoder(cfg, V.random_weights(cfg, 20), device=device), cfg.out_dim
 
 
-def build_workload(args, rank, world_size, device):
-    import torch
-    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
-    from ibloc_amd.registration import CloudBatch, RegContext
-    from ibloc_amd.synth import SynthWorld
-
-    t0 = time.time()
-    enc, dim = make_encoder(args.model, device)
-    world = SynthWorld(args.memory, pts_per_object=max(args.points, 16), E=args.views, D=dim, seed=21,
-                       sample_points=args.register, spacing=args.spacing)
-    rng = np.random.default_rng(21)
-    crops = Crops(args.model, 21)
-    # query batches first (distinct per step and per rank): they tell which instances are ever looked at
-    frames = []
-    frng = np.random.default_rng(1000 + rank)
-    for step in range(args.warmup + args.steps):
-        frames.append([world.make_frame(frng, q=args.q, pts_per_object=args.points, with_clouds=args.register) for _ in range(args.frames)])
-    # memory embeddings = the encoder's embeddings of E noisy views of every instance.  An embedding-only memory of 50 000
-    # instances (config C4) would need 200 000 synthetic crops that no query ever looks at: there only the instances that occur in
-    # a query frame (of any rank) are embedded, the others keep the generator's random unit embeddings -- throughput is unaffected
-    # (the match streams every row either way), the accuracy fields then describe the embedded instances only
+def embed_memory(args, world, world_size, enc, crops, rng, device):
+    """memory embeddings = the encoder's embeddings of E noisy views of every instance"""
     embed_ids = np.arange(args.memory)
     if not args.register and args.memory > 20000:
         seen = set()
@@ -154,9 +173,45 @@ def build_workload(args, rank, world_size, device):
     if len(embed_ids) < args.memory:
         mem_emb = mem_emb * np.linalg.norm(got, axis=-1).mean()           # the scale of the encoder's (un-normalised) outputs
     mem_emb[embed_ids] = got
+    return mem_emb
+
+
+def build_workload(args, rank, world_size, device, reuse=None, n_steps=None):
+    """reuse = (encoder, dim, memory embeddings) of a workload built before: the same memory with another object spacing (the embeddings
+    of the synthetic instances do not depend on where the objects stand); n_steps: query batches to generate (default warmup + steps)"""
+    import torch
+    from ibloc_amd.engine import LocaliseEngine, MemoryShard, intensity_from_colors
+    from ibloc_amd.registration import CloudBatch, RegContext
+    from ibloc_amd.synth import SynthWorld
+
+    t0 = time.time()
+    n_steps = args.warmup + args.steps if n_steps is None else n_steps
+    if reuse is not None:
+        enc, dim, mem_emb_reused, comm_reused = reuse
+    else:
+        enc, dim = make_encoder(args.model, device)
+    world = SynthWorld(args.memory, pts_per_object=max(args.points, 16), E=args.views, D=dim, seed=21,
+                       sample_points=args.register, spacing=args.spacing)
+    rng = np.random.default_rng(21)
+    crops = VarCrops(21) if args.var_crops else Crops(args.model, 21)
+    # query batches first (distinct per step and per rank): they tell which instances are ever looked at
+    frames = []
+    frng = np.random.default_rng(1000 + rank)
+    for step in range(n_steps):
+        frames.append([world.make_frame(frng, q=args.q, pts_per_object=args.points, with_clouds=args.register) for _ in range(args.frames)])
+    # memory embeddings = the encoder's embeddings of E noisy views of every instance.  An embedding-only memory of 50 000
+    # instances (config C4) would need 200 000 synthetic crops that no query ever looks at: there only the instances that occur in
+    # a query frame (of any rank) are embedded, the others keep the generator's random unit embeddings -- throughput is unaffected
+    # (the match streams every row either way), the accuracy fields then describe the embedded instances only
+    if reuse is not None:
+        mem_emb = mem_emb_reused
+    else:
+        mem_emb = embed_memory(args, world, world_size, enc, crops, rng, device)
     ctx = RegContext(int(args.arena_gb * (1 << 30)))
     comm = None
-    if args.shard_memory and args.comm == "rccl":            # the library's own RCCL communicator instead of torch.distributed's group
+    if reuse is not None:
+        comm = comm_reused
+    elif args.shard_memory and args.comm == "rccl":          # the library's own RCCL communicator instead of torch.distributed's group
         from ibloc_amd.parallel import RcclComm
         comm = RcclComm() if world_size > 1 else RcclComm.single()
     shard = (rank, world_size) if (args.shard_memory and (world_size > 1 or comm is not None)) or args.shard_clouds else None
@@ -180,7 +235,12 @@ def build_workload(args, rank, world_size, device):
             poses.append(f["pose"])
             ids.append(f["ids"])
         det = CloudBatch.from_numpy(clouds, ints, device=device) if args.register else None
-        batches.append(dict(det=det, crops=crops.variants(crop_ids, frng, device), qs=qs, poses=poses, ids=ids))
+        if args.var_crops:
+            from ibloc_amd.vit import PackedCrops
+            host = crops.variants_host(crop_ids, frng)
+            batches.append(dict(det=det, crops=PackedCrops(host, device), crops_host=host, qs=qs, poses=poses, ids=ids))
+        else:
+            batches.append(dict(det=det, crops=crops.variants(crop_ids, frng, device), qs=qs, poses=poses, ids=ids))
     if rank == 0:
         print(f"[bench] setup {time.time() - t0:.1f}s: M={args.memory} E={args.views} pts={args.points} "
               f"frames/step={args.frames} Q={args.q} model={args.model}", file=sys.stderr)
@@ -214,7 +274,7 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
     else:
         cfg = V.CONFIGS[args.model]
         w = V.random_weights(cfg, 20)
-        crops = batch["crops"].cpu().numpy()
+        crops = batch["crops_host"] if "crops_host" in batch else batch["crops"].cpu().numpy()
 
         def embed(lo, hi):
             return vo.embed_crops(w, cfg, pp.RECIPES[cfg.recipe], list(crops[lo:hi]))
@@ -230,7 +290,7 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
         q = batch["qs"][f]
         e = embed(row, row + q)
         sims = mo.closest_similarity(mo.normalize_rows(e), mem_n, emb_off)
-        aug = np.ones((1, 7, args.memory + 1), dtype=np.float16)
+        aug = np.ones((1, 7, args.memory + 1), dtype=np.float16)          # (the library's assignment search takes 7-row frames)
         aug[0, :q, :-1] = sims
         assns = assign_batch(aug, [q], 4, 1)[0]
         if det is not None:
@@ -285,7 +345,7 @@ def main():
     ap.add_argument("--memory", type=int, default=None)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--points", type=int, default=None)
-    ap.add_argument("--q", type=int, default=7)
+    ap.add_argument("--q", type=int, default=None, help="detections per frame (default 7; C1: 4)")
     ap.add_argument("--model", default=None)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--arena-gb", type=float, default=24.0)
@@ -305,6 +365,11 @@ def main():
                     "operands (168 instead of 264 bytes per point; the feature search converts while it stages)")
     ap.add_argument("--spacing", type=float, default=2.5, help="grid spacing of the synthetic memory's objects in metres (2.5: separated "
                     "objects; ~0.7: adjacent objects whose neighbourhoods overlap, so cross-instance features are recomputed)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each: `value` is the first (the contract's), value_min / "
+                    "value_max the spread over all of them")
+    ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the extra region that copies every step's inputs from pinned host memory")
+    ap.add_argument("--adjacent-spacing", type=float, default=None, help="spacing of the second, adjacent-objects world measured after the "
+                    "timed region and reported as value_adjacent (default 0.7 for config T, 0 = skip for the other configs)")
     ap.add_argument("--ransac-budget", type=int, default=100000, help="hypotheses per job of the fixed-budget RANSAC figure (0 = skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -314,6 +379,11 @@ def main():
         if getattr(args, k) is None:
             setattr(args, k, preset[k])
     args.register = preset["register"] and args.points > 0
+    if args.q is None:
+        args.q = preset.get("q", 7)
+    args.var_crops = bool(preset.get("var_crops", False))
+    if args.adjacent_spacing is None:
+        args.adjacent_spacing = 0.7 if args.config == "T" else 0.0
 
     import torch
     import torch.distributed as dist
@@ -383,6 +453,77 @@ def main():
     total_frames = args.frames * args.steps * world_size
     value = total_frames / dt
     roof_live = prof.roofline(None)                       # before the untimed stage-timing step below adds launches
+
+    def timed_region(run):
+        """one more region of exactly K steps on the same batches, bracketed like the first: frames/s over all ranks"""
+        barrier()
+        prof.reset(enable=False)
+        t1 = time.perf_counter()
+        for _ in run():
+            pass
+        barrier()
+        d = time.perf_counter() - t1
+        if world_size > 1:
+            tt = torch.tensor([d], dtype=torch.float64, device="cpu" if share_gpu else device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return total_frames / d
+
+    # the 20-step region lasts under a second: two repeats of the same region give the run-to-run spread of `value` (VERDICT r3 #8)
+    repeats = [value] + [timed_region(lambda: run_many(args.warmup, args.warmup + args.steps)) for _ in range(max(0, args.repeats - 1))]
+    # ... and the same K steps with every step's inputs (crops, detected clouds, segment offsets) copied from PINNED HOST memory inside
+    # the timed region, on the stream the step runs on: the PCIe-inclusive rate (never `value`: the contract counts HBM-resident inputs)
+    value_h2d = None
+    if args.h2d and not args.lanes:
+        def pin(t):
+            return t.cpu().pin_memory()
+
+        host = []
+        for b in batches[args.warmup:args.warmup + args.steps]:
+            c = b["crops"]
+            hb = dict(qs=b["qs"], det_host=None, crops_host=None)
+            if b["det"] is not None:
+                hb["det_host"] = (pin(b["det"].pts4), b["det"].seg_off_host)
+            if isinstance(c, tuple):
+                hb["crops_host"] = tuple(pin(x) for x in c)
+            elif isinstance(c, torch.Tensor):
+                hb["crops_host"] = pin(c)
+            else:                                           # PackedCrops: one byte string + shapes
+                hb["crops_host"] = (pin(c.src), c.shapes, c.offs)
+            host.append(hb)
+        h2d_bytes = 0
+
+        def upload(hb):
+            nonlocal h2d_bytes
+            from ibloc_amd.registration import CloudBatch
+            det = None
+            if hb["det_host"] is not None:
+                p4, off = hb["det_host"]
+                det = CloudBatch(p4.to(device, non_blocking=True), off)
+                h2d_bytes += p4.numel() * 4
+            ch = hb["crops_host"]
+            if isinstance(ch, tuple) and len(ch) == 3 and not isinstance(ch[1], torch.Tensor):
+                from ibloc_amd.vit import PackedCrops
+                crops_d = PackedCrops(None, _src=ch[0].to(device, non_blocking=True), _shapes=ch[1], _offs=ch[2])
+                h2d_bytes += ch[0].numel()
+            elif isinstance(ch, tuple):
+                crops_d = tuple(x.to(device, non_blocking=True) for x in ch)
+                h2d_bytes += sum(x.numel() * x.element_size() for x in ch)
+            else:
+                crops_d = ch.to(device, non_blocking=True)
+                h2d_bytes += ch.numel() * ch.element_size()
+            return dict(det=det, q_per_frame=hb["qs"], crops=crops_d, seed=args.seed)
+
+        def run_h2d():
+            if args.sequential:
+                return (eng.localise_batch(u["det"], u["q_per_frame"], crops=u["crops"], seed=args.seed, **kw) for u in map(upload, host))
+            return eng.localise_stream((upload(hb) for hb in host), **kw)       # lazy: a batch is uploaded when the pipeline pulls it
+
+        for _ in run_h2d():                                 # one untimed pass: pinned staging and allocator warm
+            pass
+        h2d_bytes = 0
+        value_h2d = {"value": timed_region(run_h2d), "h2d_bytes_per_step": h2d_bytes / max(1, args.steps),
+                     "what": "the same K steps with each step's crops + detected clouds copied from pinned host memory inside the timed region"}
     roof_iso = None
     stage_roofs = []
     if not args.sequential:                               # per-stage device times of one step run back to back, outside the timed region
@@ -425,61 +566,128 @@ def main():
                                     "all correspondences (the checkers prune before scoring, as in Open3D)"})
             prof.reset(enable=False)
 
-    # accuracy signals against the generator's ground truth (outside the timed region)
-    n_frames = n_assn_ok = n_ok = n_ok_given = n_any = 0
-    clean_pts = []
-    for i, res in enumerate(all_res):
-        b = batches[args.warmup + i]
-        for f, r in enumerate(res):
-            n_frames += 1
-            ids = b["ids"][f]
-            if r.best < 0:
-                continue
-            chosen = r.assignments[r.best]
-            good = all(ids[d] == m for d, m in chosen)
-            n_any += int(any(all(ids[d] == m for d, m in a) for a in r.assignments))
-            n_assn_ok += int(good)
-            if args.register:
-                P = b["poses"][f]
-                terr = np.linalg.norm(r.pose_corrected[:3] - P[:3, 3])
-                rerr = rot_err(Rotation.from_quat(r.pose_corrected[3:]).as_matrix(), P[:3, :3])
-                ok = terr < 0.6 and rerr < 0.3            # the reference's success rule, tum_localisation_trial.py:274
-                n_ok += int(ok)
-                n_ok_given += int(ok and good)
-                clean_pts.append(r.n_clean / max(1, len(ids)))
+    def accuracy(results, bs):
+        """accuracy signals against the generator's ground truth (outside the timed regions)"""
+        n_frames = n_assn_ok = n_ok = n_ok_given = n_any = 0
+        clean_pts = []
+        for res, b in zip(results, bs):
+            for f, r in enumerate(res):
+                n_frames += 1
+                ids = b["ids"][f]
+                if r.best < 0:
+                    continue
+                chosen = r.assignments[r.best]
+                good = all(ids[d] == m for d, m in chosen)
+                n_any += int(any(all(ids[d] == m for d, m in a) for a in r.assignments))
+                n_assn_ok += int(good)
+                if args.register:
+                    P = b["poses"][f]
+                    terr = np.linalg.norm(r.pose_corrected[:3] - P[:3, 3])
+                    rerr = rot_err(Rotation.from_quat(r.pose_corrected[3:]).as_matrix(), P[:3, :3])
+                    ok = terr < 0.6 and rerr < 0.3            # the reference's success rule, tum_localisation_trial.py:274
+                    n_ok += int(ok)
+                    n_ok_given += int(ok and good)
+                    clean_pts.append(r.n_clean / max(1, len(ids)))
+        return n_frames, n_assn_ok, n_ok, n_ok_given, n_any, clean_pts
+
+    n_frames, n_assn_ok, n_ok, n_ok_given, n_any, clean_pts = accuracy(all_res, batches[args.warmup:args.warmup + args.steps])
+
+    # ---- the same workload with ADJACENT objects (VERDICT r3 #4): the default world keeps its objects 2.5 m apart, so no instance lies
+    # inside another one's feature neighbourhood and every job side is served by the resident instance features -- the best case.  On a
+    # 0.7 m grid (a desk) the features of every multi-instance job side are recomputed on the concatenation, as the reference does for
+    # every job.  Same memory embeddings, same encoder, K steps timed the same way, reported beside `value`.
+    adjacent = None
+    cpu_batch = batches[args.warmup]                       # (the CPU baseline leg below samples the default world)
+    if args.adjacent_spacing > 0 and args.register and abs(args.spacing - args.adjacent_spacing) > 1e-9:
+        import copy
+        t_adj = time.time()
+        a2 = copy.copy(args)
+        a2.spacing = args.adjacent_spacing
+        comm0 = eng.exchange.comm if eng.exchange is not None else None
+        enc0 = eng.encoder
+        eng.close()
+        eng.memory.close()
+        eng.ctx.close()                                    # the first world's arena (24 GB) and resident features go before the second is built
+        eng.memory = None
+        del batches
+        torch.cuda.empty_cache()
+        eng2, batches2, _, _ = build_workload(a2, rank, world_size, device, reuse=(enc0, mem_emb.shape[-1], mem_emb, comm0), n_steps=2 + args.steps)
+        eng = eng2                                         # (the communicator is released through this engine below)
+        items2 = [dict(det=b["det"], q_per_frame=b["qs"], crops=b["crops"], seed=args.seed) for b in batches2]
+
+        def run2(lo, hi):
+            if args.sequential:
+                return (eng2.localise_batch(b["det"], b["q_per_frame"], crops=b["crops"], seed=args.seed, **kw) for b in items2[lo:hi])
+            return eng2.localise_stream(items2[lo:hi], **kw)
+        for _ in run2(0, 2):
+            pass
+        barrier()
+        prof.reset(enable=False)
+        t1 = time.perf_counter()
+        res2 = list(run2(2, 2 + args.steps))
+        barrier()
+        d2 = time.perf_counter() - t1
+        if world_size > 1:
+            tt = torch.tensor([d2], dtype=torch.float64, device="cpu" if share_gpu else device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d2 = float(tt.item())
+        tm2 = {}
+        eng2.localise_batch(batches2[-1]["det"], batches2[-1]["qs"], crops=batches2[-1]["crops"], seed=args.seed, timings=tm2, **kw)
+        torch.cuda.synchronize()
+        nf, na, nok, nokg, nany, cp = accuracy(res2, batches2[2:2 + args.steps])
+        adjacent = {"value": total_frames / d2, "unit": "query-frames/s", "ms_per_step": d2 / args.steps * 1e3, "object_spacing_m": args.adjacent_spacing,
+                    "steps": args.steps, "assignment_correct_rate": na / max(1, nf), "localised_0.6m_0.3rad": nok / max(1, nf),
+                    "registered_given_correct_assignment": nokg / max(1, na), "det_points_after_outlier_mean": float(np.mean(cp)) if cp else None,
+                    "feature_reuse_last_step": tm2.get("reuse"),
+                    "what": "the same memory, encoder and step on objects %.2f m apart: neighbouring instances lie inside each other's feature "
+                            "neighbourhoods, so the features of every multi-instance job side are recomputed on the concatenation "
+                            "(feature_reuse: points served by resident features, points recomputed, recomputed groups, job sides, distinct "
+                            "matching pairs, pair uses)" % args.adjacent_spacing}
+        if rank == 0:
+            print(f"[bench] adjacent-objects region {time.time() - t_adj:.1f}s", file=sys.stderr)
 
     if rank == 0:
         roof = roof_live
         if roof is not None and roof_iso is not None:
             roof["note"] = ("pipelined steps: these launches share the device with the registration kernels of the previous step, so the "
                             "duration of a launch is not the kernel's own speed; roofline_isolated times the same launches alone; "
-                            "traffic: PMC counters cannot be read in-process -- traffic_from_profile is the FETCH_SIZE / WRITE_SIZE result "
-                            "of the committed rocprofv3 --pmc passes (tools/profile_pmc.sh)")
-        pmc_file = os.path.join(ROOT, "profiles", "r03", "gemm_pmc.json")
+                            "traffic: PMC counters cannot be read in-process -- it is the FETCH_SIZE / WRITE_SIZE result of the committed "
+                            "rocprofv3 --pmc passes of this build (tools/profile_pmc.sh; matched by the kernel source's hash)")
+        # roofline.traffic: the FETCH_SIZE / WRITE_SIZE figure of THIS build -- tools/profile_pmc.sh stamps profiles/r04/gemm_pmc.json with
+        # the sha256 of csrc/vit.hip it was measured on; a file measured on other kernel source is not echoed (traffic stays null)
+        pmc_file = os.path.join(ROOT, "profiles", "r04", "gemm_pmc.json")
         if roof is not None and os.path.exists(pmc_file):
             try:
+                import hashlib
                 pm = json.load(open(pmc_file))
-                tp = {"bytes_per_launch": pm.get("traffic_bytes_per_launch"), "algorithmic_bytes_per_launch": pm.get("algorithmic_bytes_per_launch"),
-                      "file": "profiles/r03/gemm_pmc.json"}
-                roof["traffic_from_profile"] = tp
-                if roof_iso is not None:
-                    roof_iso["traffic_from_profile"] = tp
+                sha = hashlib.sha256(open(os.path.join(ROOT, "instance-based-loc_amd", "csrc", "vit.hip"), "rb").read()).hexdigest()
+                if pm.get("source_sha256_vit_hip") == sha:
+                    for r_ in (roof, roof_iso):
+                        if r_ is not None:
+                            r_["traffic"] = pm.get("traffic_bytes_per_launch")
+                            r_["traffic_source"] = {"file": "profiles/r04/gemm_pmc.json", "algorithmic_bytes_per_launch": pm.get("algorithmic_bytes_per_launch"),
+                                                    "how": pm.get("how"), "source_sha256_vit_hip": sha[:16]}
+                else:
+                    roof["traffic_source"] = "profiles/r04/gemm_pmc.json was measured on other kernel source than this build's: not reported"
             except (OSError, ValueError):
                 pass
         cpu = None
         cpu_frames = args.cpu_frames if args.cpu_frames is not None else (6 if args.register else 24)
         if cpu_frames > 0 and world_size == 1:            # the CPU leg is timed on rank 0 of the single-GPU run only
-            v, cdt, threads = cpu_baseline(args, world, mem_emb, batches[args.warmup], cpu_frames)
+            v, cdt, threads = cpu_baseline(args, world, mem_emb, cpu_batch, cpu_frames)
             enc_name = "torch-cpu fp32 " + ("DATOR (two TransReID streams + fusion head)" if args.model == "dator" else "ViT")
             reg_name = "C oracle (match, FPFH, RANSAC, coloured ICP, evaluate; OpenMP) + host assignment search" if args.register \
                 else "C oracle match + host assignment search"
             cpu = {"value": v, "unit": "query-frames/s", "cores": threads, "kind": "port",
                    "sample": f"{cpu_frames} frame(s) of the same workload, {cdt:.1f} s: {enc_name} + {reg_name}"}
         stages = "FPFH+RANSAC+coloured ICP on %d-pt clouds, whole-memory evaluate" % args.points if args.register else "embed+match+assign only"
-        crop_desc = "256x128 RGB + depth crops" if args.model == "dator" else "crops 224^2"
+        crop_desc = "256x128 RGB + depth crops" if args.model == "dator" else ("crops of 64..400 px (resized on the device)" if args.var_crops else "crops 224^2")
         out = {
             "metric": "query-frames localized/sec (embed+match+register)",
             "value": value,
+            "value_min": min(repeats), "value_max": max(repeats), "value_repeats": repeats,
+            "value_with_h2d": value_h2d,
+            "value_adjacent": adjacent,
             "unit": "query-frames/s",
             "n_gpus": world_size,
             "steps": args.steps,
@@ -522,6 +730,13 @@ def main():
             # context of their job (instances within the influence radius of each other), recomputed groups, job sides
             "feature_reuse_last_step": timings.get("reuse"),
         }
+        if args.config == "C1":
+            # the only numbers that exist for the literal reference code at this scale (measured in the survey container,
+            # 8 host cores, no GPU; not reference-published and not part of cpu_baseline, which times this repo's CPU restatement)
+            out["reference_cpu_timings_survey6"] = {
+                "SimVolume construct + top-k, Q=7, M=20 (utils/similarity_volume.py, numba stubbed)": "1.41 s + 0.30 s per frame",
+                "DINOv2-B/14 architecture 224^2, batch 1, fp32 torch-cpu, 8 threads, random weights": "139 ms per crop",
+                "source": "SURVEY.md section 6"}
         print(json.dumps(out))
     if eng.exchange is not None and eng.exchange.comm is not None:       # the library's RCCL communicator: released by every rank, before
         torch.cuda.synchronize()                                            # torch's process group goes

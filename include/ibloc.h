@@ -103,6 +103,10 @@ typedef struct {
     const float* ln_f_g;   const float* ln_f_b;
     const void* w_proj;            /* fp16 [out_dim][dim] or NULL                                    */
     const void* w_patch_lo;        /* optional fp16 [dim][patch_k_pad] = (W - fp16(W)) * S: second term of the patch weights  */
+    const void* w_proj_x;          /* optional fp16 [out_dim][3*dim] = [W_hi | W_hi / S | W_lo * S]: the projection with three-term
+                                      operands (round 4: the final LayerNorm row is written as [a_hi | a_lo * S | a_hi / S]); the
+                                      projection is the last arithmetic before the output, so its fp16 roundings are not attenuated
+                                      by anything downstream (4e-4 of the embedding with plain operands) and it costs nothing     */
     ibl_vit_layer layers[IBL_VIT_MAX_LAYERS];
 } ibl_vit_weights;
 

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <mutex>
 #include <vector>
@@ -27,7 +28,9 @@ struct ProfSlot {
     hipEvent_t a, b;
     int id;
     double units;
+    bool ended;          // ibl_prof_end recorded `b` in THIS use of the (pooled) event pair; a bracket left on an error path is dropped
 };
+unsigned g_gen = 1;      // bumped by every drain: a token handed out before it no longer addresses a slot
 std::mutex g_mu;
 int g_enabled = 0;
 std::vector<ProfSlot> g_pending;
@@ -50,28 +53,34 @@ void ibl_prof_begin(int id, double units, void* stream, void** token) {
         if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return;
     }
     (void)hipEventRecord(ev.first, (hipStream_t)stream);
-    g_pending.push_back({ev.first, ev.second, id, units});
-    *token = reinterpret_cast<void*>(g_pending.size());     // 1-based index
+    g_pending.push_back({ev.first, ev.second, id, units, false});
+    *token = reinterpret_cast<void*>(((uintptr_t)g_gen << 32) | (uintptr_t)g_pending.size());     // generation | 1-based index
+}
+
+// token -> slot of the current generation, or null (stale token: the slots were drained by ibl_prof_read / ibl_prof_enable in between)
+static ProfSlot* prof_slot(void* token) {
+    const uintptr_t t = reinterpret_cast<uintptr_t>(token);
+    const size_t i = (size_t)(t & 0xffffffffu) - 1;
+    if ((unsigned)(t >> 32) != g_gen || i >= g_pending.size()) return nullptr;
+    return &g_pending[i];
 }
 
 void ibl_prof_end(void* token, void* stream) {
     if (!token) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    const size_t i = reinterpret_cast<size_t>(token) - 1;
-    if (i < g_pending.size()) (void)hipEventRecord(g_pending[i].b, (hipStream_t)stream);
+    if (ProfSlot* p = prof_slot(token)) p->ended = hipEventRecord(p->b, (hipStream_t)stream) == hipSuccess;
 }
 
 void ibl_prof_set_units(void* token, double units) {
     if (!token) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    const size_t i = reinterpret_cast<size_t>(token) - 1;
-    if (i < g_pending.size()) g_pending[i].units = units;
+    if (ProfSlot* p = prof_slot(token)) p->units = units;
 }
 
 static void prof_drain() {
     for (auto& p : g_pending) {
         float ms = 0.f;
-        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        if (p.ended && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             g_ms[p.id] += ms;
             g_units[p.id] += p.units;
             g_launches[p.id] += 1;
@@ -79,6 +88,7 @@ static void prof_drain() {
         g_pool.emplace_back(p.a, p.b);
     }
     g_pending.clear();
+    ++g_gen;
 }
 
 extern "C" int ibl_prof_enable(int on) {

@@ -1214,14 +1214,19 @@ extern "C" int ibl_register_batch_ids(ibl_reg_ctx* ctx, const float* det_pts4, c
     return st;
 }
 
-extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
-                                         int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
-                                         int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs,
-                                         double voxel_size, double global_dist_factor, double local_dist_factor, uint64_t seed,
-                                         uint32_t job_id_base, int64_t ransac_max_iter, int flags,
-                                         const ibl_instance_features* det_features, const ibl_instance_features* mem_features,
-                                         double* T_out, double* rmse_out, double* fitness_out, double* means_out, double* T_ransac_out,
-                                         int64_t* ransac_stats_out, int64_t* reuse_stats_out, void* stream) {
+// One pass of the registration call.  *redo (bits REDO_*) tells the caller that the results of this pass are unusable and which
+// of the two overflowing lists to avoid in the next one; the pass has released its arena allocations by then (the redo used
+// to recurse from inside the pass, with the first pass's allocations still stacked under the second's).
+enum { REDO_RANSAC_FULL_LIST = 1, REDO_FEAT_VALU = 2 };
+static int register_batch_cached_pass(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                                      int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                                      int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs,
+                                      double voxel_size, double global_dist_factor, double local_dist_factor, uint64_t seed,
+                                      uint32_t job_id_base, int64_t ransac_max_iter, int flags,
+                                      const ibl_instance_features* det_features, const ibl_instance_features* mem_features,
+                                      double* T_out, double* rmse_out, double* fitness_out, double* means_out, double* T_ransac_out,
+                                      int64_t* ransac_stats_out, int64_t* reuse_stats_out, void* stream, int* redo) {
+    *redo = 0;
     if (!ctx || !det_pts4 || !mem_pts4 || !det_off_dev || !mem_off_dev || !det_off_host || !mem_off_host || !job_src_seg || !job_tgt_seg ||
         !T_out || !rmse_out || !fitness_out)
         return ibl_set_error(IBL_ERR_ARG, "ibl_register_batch: null pointer");
@@ -1890,33 +1895,15 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         ibl_prof_set_units(tok_icp, icp_b);
         ibl_prof_set_units(tok_ransac, hyp);
     }
-    if ((h_status & IBL_ST_RANSAC_OVERFLOW) && !tl_ransac_full_list) {
-        // more edge-test survivors in one round than the list holds (near-identical clouds, a loose edge criterion): the results of this
-        // pass are unusable -- once more with a list that holds every hypothesis of a round (same hypotheses, same fold order: same result
-        // as a pass whose list never overflowed)
-        tl_ransac_full_list = true;
-        hipLaunchKernelGGL(ibl_status_set_kernel, dim3(1), dim3(1), 0, s, ctx->d_status, IBL_ST_RANSAC_REDONE);
-        const int st2 = ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
-                                                  job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed,
-                                                  job_id_base, ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out,
-                                                  means_out, T_ransac_out, ransac_stats_out, reuse_stats_out, stream);
-        tl_ransac_full_list = false;
-        return st2;
-    }
-    if (h_status & IBL_ST_RANSAC_OVERFLOW)
+    // Overflowed lists make the results of this pass unusable.  Both are decided here, in one place: a pass that overflowed the RANSAC
+    // survivor list (near-identical clouds, a loose edge criterion) is redone with a list that holds every hypothesis of a round (same
+    // hypotheses, same fold order: the result of a pass whose list never overflowed); one whose matrix-core feature search overflowed
+    // its candidate list is redone with the VALU search, which has none; a pass that hit both asks for both at once.
+    if ((h_status & IBL_ST_RANSAC_OVERFLOW) && tl_ransac_full_list)
         return ibl_set_error(IBL_ERR_OVERFLOW, "ransac: the surviving hypotheses of one round exceed the list capacity");
-    if ((h_status & IBL_ST_FEAT_OVERFLOW) && !tl_force_valu) {
-        // the candidate list of the matrix-core feature search overflowed (results of this pass are unusable): once more with the VALU
-        // search, which has no list
-        tl_force_valu = true;
-        hipLaunchKernelGGL(ibl_status_set_kernel, dim3(1), dim3(1), 0, s, ctx->d_status, IBL_ST_FEAT_REDONE);
-        const int st2 = ibl_register_batch_cached(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
-                                                  job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed,
-                                                  job_id_base, ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out,
-                                                  means_out, T_ransac_out, ransac_stats_out, reuse_stats_out, stream);
-        tl_force_valu = false;
-        return st2;
-    }
+    if (h_status & IBL_ST_RANSAC_OVERFLOW) *redo |= REDO_RANSAC_FULL_LIST;
+    if ((h_status & IBL_ST_FEAT_OVERFLOW) && !tl_force_valu) *redo |= REDO_FEAT_VALU;
+    if (*redo) return IBL_OK;
     for (int j = 0; j < J; ++j) {
         for (int i = 0; i < 16; ++i) T_out[16 * j + i] = h_is[j].T[i];
         rmse_out[j] = h_is[j].rmse;
@@ -1930,6 +1917,33 @@ extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4
         }
     }
     return IBL_OK;
+}
+
+extern "C" int ibl_register_batch_cached(ibl_reg_ctx* ctx, const float* det_pts4, const int32_t* det_off_dev, const int32_t* det_off_host,
+                                         int n_det_seg, const float* mem_pts4, const int32_t* mem_off_dev, const int32_t* mem_off_host,
+                                         int n_mem_seg, const int32_t* job_src_seg, const int32_t* job_tgt_seg, int n_jobs,
+                                         double voxel_size, double global_dist_factor, double local_dist_factor, uint64_t seed,
+                                         uint32_t job_id_base, int64_t ransac_max_iter, int flags,
+                                         const ibl_instance_features* det_features, const ibl_instance_features* mem_features,
+                                         double* T_out, double* rmse_out, double* fitness_out, double* means_out, double* T_ransac_out,
+                                         int64_t* ransac_stats_out, int64_t* reuse_stats_out, void* stream) {
+    // at most three passes: the first, one with the lists it asked to avoid, and one more if that pass overflowed the OTHER list
+    int st = IBL_OK;
+    for (int pass = 0; pass < 3; ++pass) {
+        int redo = 0;
+        st = register_batch_cached_pass(ctx, det_pts4, det_off_dev, det_off_host, n_det_seg, mem_pts4, mem_off_dev, mem_off_host, n_mem_seg,
+                                        job_src_seg, job_tgt_seg, n_jobs, voxel_size, global_dist_factor, local_dist_factor, seed, job_id_base,
+                                        ransac_max_iter, flags, det_features, mem_features, T_out, rmse_out, fitness_out, means_out,
+                                        T_ransac_out, ransac_stats_out, reuse_stats_out, stream, &redo);
+        if (st != IBL_OK || !redo) break;
+        if (redo & REDO_RANSAC_FULL_LIST) tl_ransac_full_list = true;
+        if (redo & REDO_FEAT_VALU) tl_force_valu = true;
+        hipLaunchKernelGGL(ibl_status_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctx->d_status,
+                           ((redo & REDO_RANSAC_FULL_LIST) ? IBL_ST_RANSAC_REDONE : 0) | ((redo & REDO_FEAT_VALU) ? IBL_ST_FEAT_REDONE : 0));
+    }
+    tl_ransac_full_list = false;
+    tl_force_valu = false;
+    return st;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -117,17 +117,21 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
     return (z * u) * 0.70710678118654752f + v * 0.5f;
 }
 
-#ifdef IBL_GEMM_STAMPS     // lab builds only (tools/perf_gemm.py --stamps): per-block phase clocks
-__device__ long long ibl_gemm_stamps[5 * 8192];
+#ifdef IBL_GEMM_STAMPS     // lab builds only (tools/perf_gemm.py --stamps): phase clocks of every tile a (persistent) block walks
+// [block < 512][tile iteration < 16][4]: 0 = tile loop top, 1 = first stage landed (after the barrier), 2 = K loop done, 3 = epilogue issued
+__device__ long long ibl_gemm_stamps[512 * 16 * 4];
+__device__ int ibl_gemm_stamp_iter[512];
 #define GEMM_STAMP(k)                                                                                  \
     do {                                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                   \
-            ibl_gemm_stamps[5 * blockIdx.x + (k)] = (long long)__builtin_amdgcn_s_memtime();           \
-            if ((k) == 0) ibl_gemm_stamps[5 * blockIdx.x + 4] = (long long)__smid();                   \
-        }                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 512 && stamp_it < 16)                                     \
+            ibl_gemm_stamps[(blockIdx.x * 16 + stamp_it) * 4 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
 extern "C" int ibl_gemm_stamps_read(long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ibl_gemm_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -1;
+}
+extern "C" int ibl_gemm_stamps_clear() {
+    static long long zeros[512 * 16 * 4];
+    return hipMemcpyToSymbol(HIP_SYMBOL(ibl_gemm_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
 }
 #else
 #define GEMM_STAMP(k)
@@ -213,7 +217,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
 
     f32x4 acc[MI][4];      // [m-tile i][n-tile j]
     const int nk = K / BK;
-    GEMM_STAMP(0);
     constexpr int NP = GA + GW;
     const int fr = lane & 15, fg = lane >> 4;
     int arow[MI], wrow[4];
@@ -249,7 +252,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     constexpr int NSLOT = N2B + MI;
     static_assert(!PIPE || NP <= 2 * NSLOT, "pieces per stage exceed the slots of a step");
     bool first_tile = true;
+#ifdef IBL_GEMM_STAMPS
+    int stamp_it = 0;
+#endif
     for (;;) {
+    GEMM_STAMP(0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -417,6 +424,73 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     if (NAT) {
         // x[row][n] += scale[n] * (acc + bias[n]); lane (fr, fg) owns columns 16 j + 4 fg + 0..3 of n-tile j
         const int nb = ecol0 + wn * 64 + 4 * fg;
+#ifndef IBL_GEMM_EPI_SERIAL
+        // Round 4.  The read-modify-write used to run as eight dependent rounds (4 loads, wait, 4 stores per 16-row group -- and vmcnt counts
+        // stores too on gfx9, so every round also waited for the previous round's stores): ~16 exposed memory latencies, 34 k clocks per tile
+        // at K = 768 where the whole K loop is 35 k.  Now: the increments are formed in place in the accumulators (bias / scale registers
+        // die), then the 32 float4 of the residual tile are requested in three batches (12 + 12 + 8) with two batches always in flight,
+        // and a batch's stores are issued after the NEXT batch's loads: three exposed latencies.  (16 + 16 spilled: the K loop's
+        // 254 registers leave 96 beside the accumulators.)  The last row of tiles keeps the masked serial form.
+        {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 b4 = epi.bias ? *reinterpret_cast<const float4*>(epi.bias + nb + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 s4 = epi.scale ? *reinterpret_cast<const float4*>(epi.scale + nb + 16 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    acc[i][j][0] = (acc[i][j][0] + b4.x) * s4.x; acc[i][j][1] = (acc[i][j][1] + b4.y) * s4.y;
+                    acc[i][j][2] = (acc[i][j][2] + b4.z) * s4.z; acc[i][j][3] = (acc[i][j][3] + b4.w) * s4.w;
+                }
+            }
+        }
+        if (erow0 + BM <= M) {                                     // full tile (all but the last row of tiles): no row is clamped or masked
+            constexpr int B0 = MI == 8 ? 3 : 2, B1 = MI == 8 ? 3 : 2;  // 16-row groups of batch A, batch B; the rest is batch C (in A's registers)
+            float* const obase = reinterpret_cast<float*>(epi.out) + (int64_t)(erow0 + wm * (MI * 16) + fr) * epi.ldo + nb;
+            const int64_t gstride = 16 * epi.ldo;
+            float4 xa[B0][4], xb[B1][4];
+#pragma unroll
+            for (int i = 0; i < B0; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xa[i][j] = *reinterpret_cast<const float4*>(obase + i * gstride + 16 * j);
+#pragma unroll
+            for (int i = 0; i < B1; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xb[i][j] = *reinterpret_cast<const float4*>(obase + (B0 + i) * gstride + 16 * j);
+            __builtin_amdgcn_sched_barrier(0);
+#define RESID_STORE(X, I)                                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                           \
+                *reinterpret_cast<float4*>(obase + (I) * gstride + 16 * j) = make_float4(X[j].x + acc[I][j][0], X[j].y + acc[I][j][1], \
+                                                                                         X[j].z + acc[I][j][2], X[j].w + acc[I][j][3]);
+#pragma unroll
+            for (int i = 0; i < B0; ++i) { RESID_STORE(xa[i], i) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI - B0 - B1; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xa[i][j] = *reinterpret_cast<const float4*>(obase + (B0 + B1 + i) * gstride + 16 * j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < B1; ++i) { RESID_STORE(xb[i], B0 + i) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI - B0 - B1; ++i) { RESID_STORE(xa[i], B0 + B1 + i) }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
+                if (row >= M) continue;
+                float* orow = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + nb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4* o = reinterpret_cast<float4*>(orow + 16 * j);
+                    float4 x = *o;
+                    x.x += acc[i][j][0]; x.y += acc[i][j][1]; x.z += acc[i][j][2]; x.w += acc[i][j][3];
+                    *o = x;
+                }
+            }
+        }
+#undef RESID_STORE
+#else
         float4 b4[4], s4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -437,10 +511,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
                 *o = x;
             }
         }
-#ifdef IBL_GEMM_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        GEMM_STAMP(3);
 #endif
     } else if (PAIR) {
         const int nb = ecol0 + wn * 64 + 8 * fg;
@@ -472,11 +542,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
                                (unsigned)f2h(v[4]) | ((unsigned)f2h(v[5]) << 16), (unsigned)f2h(v[6]) | ((unsigned)f2h(v[7]) << 16));
             }
         }
-#ifdef IBL_GEMM_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        GEMM_STAMP(3);
-#endif
     } else {
     const int n0 = ecol0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
     float bias[16], scale[16];
@@ -543,12 +608,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
             for (int q = 0; q < 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
     }
-#ifdef IBL_GEMM_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    GEMM_STAMP(3);
-#endif
     }
+    GEMM_STAMP(3);                 // epilogue issued (its stores drain under the next tile's top wait)
+#ifdef IBL_GEMM_STAMPS
+    ++stamp_it;
+#endif
     if (!has_next) break;
     first_tile = false;
     }
@@ -1118,11 +1182,19 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
     const dim3 cls_grid((unsigned)((batch + 3) / 4));
     if (d->flags & IBL_VIT_PROJ) {
         if (!(d->flags & IBL_VIT_FINAL_LN)) return ibl_set_error(IBL_ERR_UNSUPPORTED, "projection needs final LN");
+        GemmEpi e{};
+        e.bias = nullptr; e.out = out; e.ldo = d->out_dim;
+        if (w->w_proj_x) {           // three-term operands: K' = 3 D, one accumulation (xn is free by now: batch <= R rows of 3 D)
+            hipLaunchKernelGGL((ibl_layernorm_kernel<false, 3>), cls_grid, dim3(256), 0, s, x, (int64_t)T * D, (int64_t)batch, D,
+                               w->ln_f_g, w->ln_f_b, d->ln_eps, (void*)xn, (int64_t)3 * D);
+            IBL_LAUNCH_CHECK();
+            e.algo_k = D;
+            return launch_gemm<EPI_BIAS_F32>(xn, (int64_t)3 * D, reinterpret_cast<const u16*>(w->w_proj_x), (int64_t)3 * D, batch, d->out_dim,
+                                             3 * D, e, s);
+        }
         hipLaunchKernelGGL(ibl_layernorm_kernel<false>, cls_grid, dim3(256), 0, s, x, (int64_t)T * D, (int64_t)batch, D,
                            w->ln_f_g, w->ln_f_b, d->ln_eps, (void*)fin_bf, (int64_t)D);
         IBL_LAUNCH_CHECK();
-        GemmEpi e{};
-        e.bias = nullptr; e.out = out; e.ldo = d->out_dim;
         return launch_gemm<EPI_BIAS_F32>(fin_bf, D, reinterpret_cast<const u16*>(w->w_proj), D, batch, d->out_dim, D, e, s);
     }
     if (d->flags & IBL_VIT_FINAL_LN) {

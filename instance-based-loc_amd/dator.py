@@ -19,6 +19,8 @@ MIN_DEPTH, MAX_DEPTH = 0.0, 50.0
 STREAM_CFG = V.VitConfig("transreid_b16", 768, 12, 12, 3072, 16, 256, 128, (16, 8), layerscale=False, final_ln=False,
                          n_blocks_run=11, out_all_tokens=True, recipe="dator_rgb")
 
+DEFAULT_PRECISION = V.DEFAULT_PRECISION
+
 HEAD_LINEARS = ["proj_local_rgb", "proj_global_rgb", "merge_rgb", "proj_local_depth", "proj_global_depth", "merge_depth",
                 "Q_r", "V_r", "Q_d", "V_d"]
 ATTN_OPS = ["r2r", "d2d", "d2r", "r2d"]
@@ -140,10 +142,13 @@ class DatorHeadWeights(C.Structure):
 
 
 class DatorEncoder:
-    def __init__(self, rgb_weights: dict, depth_weights: dict, head_weights: dict, device="cuda"):
+    def __init__(self, rgb_weights: dict, depth_weights: dict, head_weights: dict, device="cuda", precision=None):
+        """precision: operand-term plan of the two streams (ibloc_amd.vit syntax; None = $IBL_VIT_PREC or DEFAULT_PRECISION below)"""
+        import os
         self.device = torch.device(device)
-        self.rgb = V.VitEncoder(STREAM_CFG, fold_lora(rgb_weights), device=device)
-        self.depth = V.VitEncoder(STREAM_CFG, fold_lora(depth_weights), device=device)
+        self.precision = precision if precision is not None else os.environ.get("IBL_VIT_PREC", DEFAULT_PRECISION)
+        self.rgb = V.VitEncoder(STREAM_CFG, fold_lora(rgb_weights), device=device, precision=self.precision)
+        self.depth = V.VitEncoder(STREAM_CFG, fold_lora(depth_weights), device=device, precision=self.precision)
         self._keep = []
         H = DatorHeadWeights()
         for name, _ in DatorHeadWeights._fields_:

@@ -56,30 +56,26 @@ def resample_table(in_size: int, out_size: int, filt: str, win0: int, win_n: int
     support = fsupport * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     ss = 1.0 / filterscale
+    # all output samples at once (round 4: the per-sample Python loop cost 6 ms per crop -- a C1 step of 128 differently sized crops
+    # spent 0.7 s on the host building tables); the arithmetic is the same float64 sequence per sample, including the left-to-right
+    # sum of the weights (np.add.accumulate adds in order; the zero padding behind a row's taps does not change it)
     rec = np.zeros((win_n, 2 + ksize), dtype=np.int32)
-    for i in range(win_n):
-        xx = win0 + i
-        center = (xx + 0.5) * scale
-        xmin = int(center - support + 0.5)
-        if xmin < 0:
-            xmin = 0
-        xmax = int(center + support + 0.5)
-        if xmax > in_size:
-            xmax = in_size
-        xmax -= xmin
-        xs = np.arange(xmax, dtype=np.float64)
-        w = fn((xs + xmin - center + 0.5) * ss)
-        ww = 0.0
-        for v in w:           # sequential sum, like the C loop
-            ww += v
-        if ww != 0.0:
-            w = w / ww
-        k = np.where(w < 0, (-0.5 + w * (1 << PRECISION_BITS)).astype(np.int64),
-                     (0.5 + w * (1 << PRECISION_BITS)).astype(np.int64))
-        # C casts double -> int by truncation toward zero; astype(int64) truncates toward zero as well
-        rec[i, 0] = xmin
-        rec[i, 1] = xmax
-        rec[i, 2:2 + xmax] = k
+    center = (win0 + np.arange(win_n, dtype=np.float64) + 0.5) * scale
+    xmin = (center - support + 0.5).astype(np.int64)            # C's (int) cast: truncation toward zero
+    xmin[xmin < 0] = 0
+    xmax = (center + support + 0.5).astype(np.int64)
+    xmax[xmax > in_size] = in_size
+    xmax -= xmin
+    xs = np.arange(ksize, dtype=np.float64)[None, :]
+    taps = xs < xmax[:, None]
+    w = fn((xs + xmin[:, None] - center[:, None] + 0.5) * ss) * taps
+    ww = np.add.accumulate(w, axis=1)[:, -1]
+    nz = ww != 0.0
+    w[nz] = w[nz] / ww[nz, None]
+    k = np.where(w < 0, (-0.5 + w * (1 << PRECISION_BITS)).astype(np.int64), (0.5 + w * (1 << PRECISION_BITS)).astype(np.int64))
+    rec[:, 0] = xmin
+    rec[:, 1] = xmax
+    rec[:, 2:] = np.where(taps, k, 0)
     return rec, ksize
 
 
@@ -132,6 +128,19 @@ class CropDesc(C.Structure):
                 ("h_ksize", C.c_int32), ("v_table", C.c_int32), ("v_ksize", C.c_int32), ("tmp_offset", C.c_int64)]
 
 
+_TABLES = {}            # (in_size, out_size, filter, window) -> (records, ksize): crop sizes recur from batch to batch
+
+
+def _cached_table(in_size, out_size, filt, win0, win_n):
+    key = (in_size, out_size, filt, win0, win_n)
+    t = _TABLES.get(key)
+    if t is None:
+        t = resample_table(in_size, out_size, filt, win0, win_n)
+        if len(_TABLES) < 8192:
+            _TABLES[key] = t
+    return t
+
+
 class TableCache:
     """Packs resample tables of a batch into one int32 array, sharing identical tables."""
 
@@ -147,7 +156,7 @@ class TableCache:
         if in_size == out_size:
             val = (win0, 0)               # identity pass: table field carries the window start
         else:
-            rec, ksize = resample_table(in_size, out_size, filt, win0, win_n)
+            rec, ksize = _cached_table(in_size, out_size, filt, win0, win_n)
             val = (self.size, ksize)
             self.chunks.append(rec.reshape(-1))
             self.size += rec.size

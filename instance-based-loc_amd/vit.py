@@ -38,17 +38,17 @@ class VitLayer(C.Structure):
 
 class VitWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w_patch", "b_patch", "cls_pos", "pos_patch", "ln_pre_g", "ln_pre_b",
-                                          "ln_f_g", "ln_f_b", "w_proj", "w_patch_lo")] + [("layers", VitLayer * MAX_LAYERS)]
+                                          "ln_f_g", "ln_f_b", "w_proj", "w_patch_lo", "w_proj_x")] + [("layers", VitLayer * MAX_LAYERS)]
 
 
 SPLIT_SCALE = 64.0          # IBL_VIT_SPLIT_SCALE (include/ibloc.h)
 
-# Which operands of which blocks get a second fp16 term ("p<terms>;<layer>:<qkv><o><fc1><fc2>;..."; qkv / fc1: 1, 2 (weights) or 3
+# Which operands of which blocks get a second fp16 term ("p<terms>;<layer>:<qkv><o><fc1><fc2>;...", layer "*" = every other block; qkv / fc1: 1, 2 (weights) or 3
 # (weights + LayerNorm output), o / fc2 / p(atch embedding): 1 or 2 (weights)).  Measured on the 12-layer ViT-B/14 with the seeded
 # random-init weights (DESIGN (c), tools/sim_vit_rounding.py): the residual stream is small in the first blocks, so the patch
 # embedding (18 % of the error variance at 1.3 % of the FLOPs), block 0 (46 %) and block 1 (14 %) carry most of the fp16 rounding
 # error of the embedding; the default gives them exact weights where that is cheap.  "plain" = one term everywhere (rounds 1-2).
-DEFAULT_PRECISION = "p2;0:3222;1:2211"
+DEFAULT_PRECISION = "p2;0:3232;1:2222"
 
 
 def parse_precision(spec):
@@ -69,7 +69,7 @@ def parse_precision(spec):
             t = tuple(int(c) for c in t)
             if len(t) != 4 or not all(1 <= v <= 3 for v in t) or t[1] > 2 or t[3] > 2:
                 raise ValueError(f"bad precision entry {part!r}")
-            layers[int(l)] = t
+            layers["*" if l.strip() == "*" else int(l)] = t      # "*": every block without an entry of its own
     if patch not in (1, 2):
         raise ValueError("patch terms: 1 or 2")
     return patch, layers
@@ -214,6 +214,31 @@ def interpolate_pos_embed(pos: np.ndarray, cfg: VitConfig) -> np.ndarray:
     return np.concatenate([cls_pos, patch_new], axis=0).astype(np.float32)
 
 
+class PackedCrops:
+    """A list of differently sized HxWx3 uint8 crops as ONE device-resident byte string + their shapes: what `VitEncoder.preprocess`
+    uploads for a list of arrays, done once (a query batch whose crops already sit in HBM).  Slices like a list."""
+
+    def __init__(self, crops, device="cuda", _src=None, _shapes=None, _offs=None):
+        if _src is not None:
+            self.src, self.shapes, self.offs = _src, _shapes, _offs
+            return
+        self.shapes = [tuple(c.shape[:2]) for c in crops]
+        self.offs = np.concatenate([[0], np.cumsum([h * w * 3 for h, w in self.shapes])]).astype(np.int64)
+        flat = np.concatenate([np.ascontiguousarray(c, dtype=np.uint8).reshape(-1) for c in crops]) if crops else np.zeros(0, np.uint8)
+        self.src = torch.from_numpy(flat).to(device)
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice):
+            raise TypeError("PackedCrops supports slices only")
+        lo, hi, step = sl.indices(len(self.shapes))
+        assert step == 1
+        return PackedCrops(None, _src=self.src[int(self.offs[lo]):int(self.offs[hi])], _shapes=self.shapes[lo:hi],
+                           _offs=self.offs[lo:hi + 1] - self.offs[lo])
+
+
 class VitEncoder:
     """Device-resident weights + batched forward through the C-ABI."""
 
@@ -254,6 +279,8 @@ class VitEncoder:
             W.ln_f_g, W.ln_f_b = dev_f32(weights["ln_f.g"]), dev_f32(weights["ln_f.b"])
         if cfg.proj_dim:
             W.w_proj = dev_f16(weights["proj.w"])
+            if self.precision != "plain":      # the last arithmetic before the output: three-term operands (free at batch x dim x out_dim)
+                W.w_proj_x = dev_f16(split_terms(weights["proj.w"], 3))
         for l in range(cfg.depth):
             p = f"l{l}."
             L = W.layers[l]
@@ -267,8 +294,8 @@ class VitEncoder:
             if cfg.layerscale:
                 L.ls1, L.ls2 = dev_f32(weights[p + "ls1"]), dev_f32(weights[p + "ls2"])
             nrun_ = cfg.depth if cfg.n_blocks_run < 0 else cfg.n_blocks_run
-            if l in layer_terms and not (l == nrun_ - 1 and not cfg.out_all_tokens):     # the CLS-only last block stays plain
-                tq, to, t1, t2 = layer_terms[l]
+            if (l in layer_terms or "*" in layer_terms) and not (l == nrun_ - 1 and not cfg.out_all_tokens):     # the CLS-only last block stays plain
+                tq, to, t1, t2 = layer_terms[l] if l in layer_terms else layer_terms["*"]
                 ones = np.ones(cfg.dim, dtype=np.float32)
                 if tq > 1:
                     L.w_qkv_x = dev_f16(split_terms(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0), tq))
@@ -301,7 +328,9 @@ class VitEncoder:
         """crops: list of HxWx3 uint8 numpy arrays (RGB as the detector hands them over), or a single
         uint8 device/host tensor (N, H, W, 3) of equally sized crops.  Returns fp16 patch matrix (device)."""
         r = self.recipe
-        if isinstance(crops, torch.Tensor):
+        if isinstance(crops, PackedCrops):
+            shapes, src = crops.shapes, crops.src.to(self.device)
+        elif isinstance(crops, torch.Tensor):
             n, h, w, _ = crops.shape
             shapes = [(h, w)] * n
             src = crops.to(self.device).contiguous().view(-1)
@@ -378,6 +407,8 @@ class VitEncoder:
         20.2 ms for 224 crops).  Off by default: the kernels of the two chains share the GPU, so per-kernel timings (the bench's
         roofline line) no longer describe one kernel.  Same arithmetic per crop either way."""
         n = crops.shape[0] if isinstance(crops, torch.Tensor) else len(crops)
+        if n == 0:
+            return torch.empty((0, self.cfg.out_dim), dtype=torch.float32, device=self.device)
         if streams > 1 and min_split <= n <= max_batch:
             if not hasattr(self, "_streams") or len(self._streams) != streams:
                 self._streams = [torch.cuda.Stream(device=self.device) for _ in range(streams)]

@@ -665,6 +665,41 @@ void oracle_evaluate(const float* src, int ns, const float* tgt, int nt, const d
     grid_free(&g);
 }
 
+/* Diagnostics for tests/test_open3d_fp64.py (the discrete decisions of the fp32 rule, to be counted against an independent fp64
+ * restatement): the hybrid neighbour SETS (idx [n][max_nn], -1 padded, in (d2, idx) order; cnt [n] = all points inside the radius when
+ * max_nn >= n) and the accepted correspondence of every transformed source point (corr [ns] = target index or -1). */
+void oracle_hybrid_sets(const float* pts, int n, double radius, int max_nn, int32_t* idx, int32_t* cnt) {
+    grid_t g;
+    grid_build(&g, pts, n, (float)radius);
+    const float r2 = (float)(radius * radius);
+#pragma omp parallel
+    {
+        nb_t* buf = (nb_t*)malloc(sizeof(nb_t) * (size_t)(n > 0 ? n : 1));
+#pragma omp for schedule(dynamic, 64)
+        for (int i = 0; i < n; ++i) {
+            int k = hybrid_search(&g, pts, pts + 3 * i, r2, max_nn, (float)radius, buf, n);
+            cnt[i] = k;
+            for (int t = 0; t < max_nn; ++t) idx[(size_t)i * max_nn + t] = t < k ? buf[t].idx : -1;
+        }
+        free(buf);
+    }
+    grid_free(&g);
+}
+
+void oracle_correspondences(const float* src, int ns, const float* tgt, int nt, const double T[16], double max_dist, int32_t* corr) {
+    grid_t g;
+    grid_build(&g, tgt, nt, (float)max_dist);
+    const float r2 = (float)(max_dist * max_dist);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < ns; ++i) {
+        double sp[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]}, p[3];
+        xform(T, sp, p);
+        float d2;
+        corr[i] = nn_within(&g, tgt, p, r2, (float)max_dist, &d2);
+    }
+    grid_free(&g);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* coloured ICP                                                                                 */
 /* ------------------------------------------------------------------------------------------ */

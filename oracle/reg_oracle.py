@@ -88,6 +88,24 @@ def evaluate(src, tgt, T, max_dist=0.02):
     return rmse.value, fit.value        # order of utils/fpfh_register.py:150
 
 
+def hybrid_sets(pts, radius, max_nn):
+    """the fp32 rule's neighbour sets: (idx [n][max_nn] padded with -1 in (d2, index) order, count [n])"""
+    pts = _f32(pts)
+    idx = np.full((len(pts), max_nn), -1, dtype=np.int32)
+    cnt = np.zeros(len(pts), dtype=np.int32)
+    lib.oracle_hybrid_sets(_p(pts), C.c_int(len(pts)), C.c_double(radius), C.c_int(max_nn), _p(idx), _p(cnt))
+    return idx, cnt
+
+
+def correspondences(src, tgt, T, max_dist):
+    """the fp32 rule's accepted correspondence (target index or -1) of every transformed source point"""
+    src, tgt = _f32(src), _f32(tgt)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    corr = np.zeros(len(src), dtype=np.int32)
+    lib.oracle_correspondences(_p(src), C.c_int(len(src)), _p(tgt), C.c_int(len(tgt)), _p(T), C.c_double(max_dist), _p(corr))
+    return corr
+
+
 def register_point_clouds(src, src_int, tgt, tgt_int, voxel_size, global_dist_factor=1.5, local_dist_factor=0.4, seed=0,
                           job_id=0, ransac_max_iter=4000000, have_colors=True, src_raw=None, tgt_raw=None):
     """== utils/fpfh_register.py:100-143; returns (T 4x4, inlier_rmse, fitness, T_ransac, ransac_stats).

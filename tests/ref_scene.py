@@ -54,6 +54,22 @@ def object_masks(depth, pose, objects, tol=0.01):
     return masks
 
 
+_DET_CACHE = {}
+
+
+def view_detections(view, seen):
+    """(raw clouds [(xyz float32, intensity)], pose) of the saved objects `seen` in one view -- the mask search of a view costs ~20 s on
+    the CPU, so the result is shared by the tests of one pytest process"""
+    key = (int(view), tuple(seen))
+    if key not in _DET_CACHE:
+        from oracle import depth_oracle as do
+        objs = memory_objects()
+        depth, rgb, pose = views()[view]
+        masks = object_masks(depth, pose, objs)
+        _DET_CACHE[key] = (do.mask_clouds(depth, rgb, [masks[j] for j in seen], FX, FY), pose)
+    return _DET_CACHE[key]
+
+
 def pose_error(pose7, T):
     """(translation error in metres, rotation error in radians) of a [x y z qx qy qz qw] pose against a 4x4 matrix"""
     R = Rotation.from_quat(pose7[3:]).as_matrix()

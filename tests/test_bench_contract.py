@@ -32,13 +32,15 @@ def test_bench_gpus_2_starts_two_ranks_and_fails_loudly_without_a_gpu():
     on this GPU-less box every rank stops with the "needs an MI355X" message (--gpus was parsed and never read)"""
     import subprocess
     import sys
+    import pytest
+    import torch
+    if torch.cuda.device_count() > 0:      # on a GPU box the run would start real bench ranks next to this process: nothing to check here
+        pytest.skip("checks the GPU-less failure path")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
                          capture_output=True, text=True, timeout=300)
-    import torch
-    if torch.cuda.is_available():          # (on a GPU box the run would succeed or fail for other reasons: nothing to check here)
-        return
     assert out.returncode != 0
     assert "starting 2 ranks" in out.stderr and "--nproc-per-node=2" in out.stderr
-    assert out.stderr.count("needs an MI355X") == 2, out.stderr[-2000:]
+    # torchrun terminates the second rank as soon as the first one exits, so only ONE message is guaranteed (ADVICE r3)
+    assert out.stderr.count("needs an MI355X") >= 1, out.stderr[-2000:]
     assert not out.stdout.strip().startswith("{")           # no JSON line from a failed run

@@ -134,6 +134,23 @@ def test_assignment_flip_rate_fp16_encoder_vs_fp32_oracle(M, F):
     assert abs(all_correct[0] - all_correct[1]) <= 0.05        # ... and the lists are equally right on both sides
 
 
+@pytest.mark.parametrize("name,bound", [("vit_b16", 1e-3), ("clip_b32", 1e-3), ("dinov2_vits14", 1e-3)])
+def test_embedding_gate_of_the_other_encoders_on_u8_crops(name, bound):
+    """SURVEY 8d's 1e-3 gate on u8-crop statistics for ViT-B/16 (utils/embeddings.py:74-98), CLIP ViT-B/32 (:31-50; the 512-d projection
+    with three-term operands since round 4) and DINOv2 ViT-S/14 (BASELINE configs[0]): every one of 896 crops against the fp32 forward.
+    Measured (profiles/r04/precision_models*.txt): 7.3e-4 mean / 8.2e-4 max, 7.3e-4 / 9.6e-4, 6.7e-4 / 8.2e-4 with the round-3 plan."""
+    from ibloc_amd import vit as V
+    cfg = V.CONFIGS[name]
+    w = V.random_weights(cfg, 20)
+    wt = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)).cuda() for k, v in w.items()}
+    enc = V.VitEncoder(cfg, w)
+    ids = np.random.default_rng(3).integers(0, 100000, size=896)
+    hip, ora = _embed_both(enc, wt, cfg, GpuCrops(21).variants(ids))
+    rel = np.linalg.norm(hip - ora, axis=1) / np.linalg.norm(ora, axis=1)
+    print(f"[gate {name}] precision plan {enc.precision}: embedding rel-L2 mean {rel.mean():.2e} max {rel.max():.2e} over {rel.size} crops")
+    assert rel.max() < bound and rel.mean() < 0.85 * bound
+
+
 def test_similarity_rows_vs_the_literal_numpy_transcript():
     """identical embeddings on both sides: np.dot (fp32) -> max over the instance's views -> fp16 (object_memory.py:922-936,
     similarity_volume.py:13-18) against ibl_closest_similarity"""

@@ -46,9 +46,7 @@ def test_oracle_registers_a_real_view_against_the_saved_objects(view, objs_seen)
     symmetric about the vertical axis (its single-object registration lands half a turn off, on either implementation), which is why
     the reference registers assignments of up to three objects: view 1 uses the armchair and the table together."""
     objs = rs.memory_objects()
-    depth, rgb, pose = rs.views()[view]
-    masks = rs.object_masks(depth, pose, objs)
-    clouds = do.mask_clouds(depth, rgb, [masks[j] for j in objs_seen], rs.FX, rs.FY)
+    clouds, pose = rs.view_detections(view, objs_seen)
     det, cols = [], []
     for pts, inten in clouds:
         keep = ro.radius_outlier(pts, 0.05, 8)

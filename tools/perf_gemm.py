@@ -39,13 +39,24 @@ for name, n_out, n_in, epi in shapes:
     print(f"{name:5s} N={n_out:5d} K={n_in:5d} epi={epi}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s")
     if STAMPS:
         from ibloc_amd import _lib
-        nb = min(8192, ((rows + 255) // 256) * (n_out // 256))
-        buf = np.zeros(5 * nb, dtype=np.int64)
-        _lib.lib.ibl_gemm_stamps_read(ctypes.c_void_p(buf.ctypes.data), ctypes.c_int(5 * nb))
-        st = buf.reshape(nb, 5)
-        t0 = st[:, 0].min()
-        d = np.diff(st[:, :4], axis=1).astype(np.float64)            # s_memtime ticks
-        print(f"      blocks {nb}: prologue {d[:, 0].mean():.0f}, k-loop {d[:, 1].mean():.0f}, epilogue+drain "
-              f"{d[:, 2].mean():.0f} clocks per block; "
-              f"k-loop min/max {d[:, 1].min():.0f}/{d[:, 1].max():.0f}")
+        buf = np.zeros(512 * 16 * 4, dtype=np.int64)
+        _lib.lib.ibl_gemm_stamps_clear()
+        V.linear_f16(x, W, b, epi, out=out)
+        torch.cuda.synchronize()
+        _lib.lib.ibl_gemm_stamps_read(ctypes.c_void_p(buf.ctypes.data), ctypes.c_int(buf.size))
+        st = buf.reshape(512, 16, 4).astype(np.float64)
+        used = st[:, :, 3] > 0                                            # (block, tile iteration) pairs that ran
+        t0 = st[:, 0, 0][st[:, 0, 0] > 0].min()
+        tiles_per_block = used.sum(1)
+        blocks = int((tiles_per_block > 0).sum())
+        top = (st[:, :, 1] - st[:, :, 0])[used]                           # tile top: wait for the first stage (+ previous stores), barrier
+        kl = (st[:, :, 2] - st[:, :, 1])[used]
+        ep = (st[:, :, 3] - st[:, :, 2])[used]
+        end = st[:, :, 3][used].max() - t0
+        first = used.copy(); first[:, 1:] = False
+        later = used & ~first
+        print(f"      {blocks} blocks x {tiles_per_block[tiles_per_block > 0].mean():.2f} tiles; s_memtime ticks (100 MHz): kernel {end:.0f}; per tile: "
+              f"top wait {top.mean():.0f} (first tile {(st[:, :, 1] - st[:, :, 0])[first].mean():.0f}, later {(st[:, :, 1] - st[:, :, 0])[later].mean() if later.any() else 0:.0f}), "
+              f"K loop {kl.mean():.0f} (min {kl.min():.0f} max {kl.max():.0f}), prologue(next) + epilogue issue {ep.mean():.0f}; "
+              f"block busy sum {(top.sum() + kl.sum() + ep.sum()) / blocks:.0f}")
 print(f"layer total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s  (x12 = {tot_ms * 12:.2f} ms)")

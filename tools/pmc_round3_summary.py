@@ -66,7 +66,10 @@ if gemm:
     json.dump({"kernel": "ibl_gemm_f16_tn (all epilogues, mean over the launches of one encoder forward)", "launches": n,
                "traffic_bytes_per_launch": tot_b / n, "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": tot_b / n / algo,
                "mean_launch_us": tot_us / n, "achieved_hbm_GBps": tot_b / (tot_us * 1e-6) / 1e9,
-               "how": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes; durations from the un-profiled kernel trace"},
+               "how": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 from separate rocprofv3 --pmc passes; durations from the un-profiled kernel trace",
+               # the kernel source these counters were collected on: bench.py reports the figure as roofline.traffic only for this source
+               "source_sha256_vit_hip": __import__("hashlib").sha256(open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(
+                   __import__("os").path.abspath(__file__))), "instance-based-loc_amd", "csrc", "vit.hip"), "rb").read()).hexdigest()},
               open(f"{out}/gemm_pmc.json", "w"), indent=1)
 split = {}
 for tag, path in (("vit", f"{pmc}/vit_mfma_counter_collection_ibl_kernels.csv"), ("reg", f"{pmc}/reg_wave_counter_collection_ibl_kernels.csv")):
