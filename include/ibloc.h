@@ -73,7 +73,9 @@ typedef struct {                   /* all [dev]; weights fp16 [N][K] row-major (
     const float* ln1_g; const float* ln1_b;
     const void* w_qkv;  const float* b_qkv;     /* [3*dim][dim] = [Wq; Wk; Wv], [3*dim]              */
     const void* w_o;    const float* b_o;       /* [dim][dim]                                         */
-    const float* ls1;                            /* [dim] or NULL                                      */
+    const float* ls1;                            /* [dim] or NULL.  NULL (no LayerScale in the model, or ls1 multiplied into the rows of
+                                                  * w_o and into b_o by the host, as ibloc_amd.vit does) selects the faster residual GEMM:
+                                                  * the residual tile is preloaded into the accumulators and the epilogue only stores   */
     const float* ln2_g; const float* ln2_b;
     const void* w_fc1;  const float* b_fc1;     /* [mlp_dim][dim]                                     */
     const void* w_fc2;  const float* b_fc2;     /* [dim][mlp_dim]                                     */
@@ -87,7 +89,8 @@ typedef struct {                   /* all [dev]; weights fp16 [N][K] row-major (
      * one accumulation, same kernel, K' = terms * dim.  The two residual GEMMs (linear epilogue) take the second weight term
      * as a second launch that accumulates scale_lo[n] * (a W_lo'^T) into the residual (scale_lo = LayerScale / S, or 1 / S). */
     const void* w_qkv_x;                         /* fp16 [3*dim][qkv_terms*dim] or NULL                */
-    const void* w_o_lo;  const float* ls1_lo;   /* fp16 [dim][dim] = W_lo * S; fp32 [dim] = ls1 / S   */
+    const void* w_o_lo;  const float* ls1_lo;   /* fp16 [dim][dim] = W_lo * S; fp32 [dim] = ls1 / S, or NULL: the term is added with the
+                                                  * factor 1 / S (no LayerScale, or LayerScale folded into W_o by the host)            */
     const void* w_fc1_x;                         /* fp16 [mlp_dim][fc1_terms*dim] or NULL              */
     const void* w_fc2_lo; const float* ls2_lo;  /* fp16 [dim][mlp_dim]; fp32 [dim]                    */
     int32_t qkv_terms, fc1_terms;                /* 1 (or 0), 2 or 3                                   */

@@ -33,10 +33,25 @@ __device__ __forceinline__ u16 f2h(float f) {
     return __builtin_bit_cast(u16, h);
 }
 
+// two fp32 -> two fp16 operands in one dword: v_cvt_pk_f16_f32 (gfx950: packed round-to-nearest-even) + packed clamp to the finite range
+// (an infinity becomes 65504: the same value f2h gives) -- three instructions per pair where med3 + cvt per element + pack took five
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned f2h_pk(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    h16x2 r = __builtin_convertvector(f32x2_{a, b}, h16x2);
+    const h16x2 hi = {(_Float16)65504.0f, (_Float16)65504.0f};
+    r = __builtin_elementwise_min(r, hi);
+    r = __builtin_elementwise_max(r, -hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+
 // ------------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] * W[N][K]^T  (+ epilogue)
 // ------------------------------------------------------------------------------------------------
-enum { EPI_BIAS_H16 = 0, EPI_BIAS_GELU_H16 = 1, EPI_RESID_F32 = 2, EPI_PATCH_F32 = 3, EPI_BIAS_F32 = 4 };
+enum { EPI_BIAS_H16 = 0, EPI_BIAS_GELU_H16 = 1, EPI_RESID_F32 = 2, EPI_PATCH_F32 = 3, EPI_BIAS_F32 = 4,
+       // x += alpha * (a W^T + bias), alpha a power of two, with the residual tile PRELOADED into the accumulators: the MFMA chain starts
+       // from (x + bias) / alpha and the epilogue is 32 plain stores per lane -- no read-modify-write after the K loop (round 4)
+       EPI_RESID_PRE_F32 = 5 };
 
 struct GemmEpi {
     const float* bias;      // [N] or null
@@ -137,6 +152,12 @@ extern "C" int ibl_gemm_stamps_clear() {
 #define GEMM_STAMP(k)
 #endif
 
+#ifndef IBL_GEMM_TOUCH
+#define IBL_GEMM_TOUCH 0            // lab (-DIBL_GEMM_TOUCH=1): L2 touches of the next tile's first stages, one tile early.  Measured: the wait
+                                    // at the tile top 6.2 -> 4.9 k clocks, but the K step that carries the touches waits for them (K loop
+                                    // 37.2 -> 37.9 k, fc1 35.6 -> 38.5 k): encoder forward 15.65 -> 16.34 ms.  The first stages are not
+                                    // late because they miss L2: 112 KB at the ~21 B / clock a CU streams into LDS take 5 k clocks
+#endif
 template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ W,
                                                                   int64_t ldw, int M, int N, int K, GemmEpi epi) {
@@ -155,7 +176,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     // wave instruction covers 64 contiguous bytes of each of its 16 output rows; with the 16-consecutive-columns-per-lane map
     // of the fp16 epilogues every float4 instruction touched 64 separate cache lines and the address coalescer (not HBM) bound
     // the epilogue: 52 k clocks per tile, more than the projection's K loop.
-    constexpr bool NAT = EPI == EPI_RESID_F32;
+    constexpr bool NAT = EPI == EPI_RESID_F32 || EPI == EPI_RESID_PRE_F32;
+    constexpr bool PRE = EPI == EPI_RESID_PRE_F32;
     // fp16 epilogues: MFMA row 4 fg + r of n-tile j is weight row 32 (j / 2) + 8 fg + 4 (j % 2) + r: a lane owns 8 consecutive
     // columns (one 16-byte store) of n-tile pair j / 2 and the four lane groups cover 64 contiguous bytes of the row
     constexpr bool PAIR = EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16;
@@ -252,15 +274,70 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     constexpr int NSLOT = N2B + MI;
     static_assert(!PIPE || NP <= 2 * NSLOT, "pieces per stage exceed the slots of a step");
     bool first_tile = true;
+    bool stores_pending = false;      // the previous tile's epilogue issued exactly 2 * MI stores per lane after this tile's first pieces
 #ifdef IBL_GEMM_STAMPS
     int stamp_it = 0;
 #endif
     for (;;) {
     GEMM_STAMP(0);
+    if constexpr (PRE) {
+        // Residual tile -> accumulators.  Per-tile stamps (round 4): the fp32 read-modify-write AFTER the K loop cost 38 k clocks of a proj
+        // tile's 85 k (eight dependent rounds of 4 loads / 4 stores per lane, each waiting for the previous round's stores: vmcnt counts
+        // stores on gfx9).  Here the 32 float4 of the tile are requested at the tile top, where the wait for the first operand stage
+        // already sits, and the epilogue only stores.  Lane (fr, fg): rows row0 + wm * 128 + 16 i + fr, columns col0 + wn * 64 + 16 j +
+        // 4 fg .. + 3 (rows beyond M read row M - 1; their lanes store nothing).
+        const int nbp = col0 + wn * 64 + 4 * fg;
+        const float ia = 1.0f / epi.alpha;                    // alpha is a power of two: exact
+        if (row0 + BM <= M) {
+            const float* const xb = reinterpret_cast<const float*>(epi.out) + (int64_t)(row0 + wm * (MI * 16) + fr) * epi.ldo + nbp;
+            const int64_t gstride = 16 * epi.ldo;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(xb + i * gstride + 16 * j);
+                    acc[i][j] = f32x4{x4.x, x4.y, x4.z, x4.w};
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int row = row0 + wm * (MI * 16) + i * 16 + fr;
+                row = row < M ? row : M - 1;
+                const float* xr = reinterpret_cast<const float*>(epi.out) + (int64_t)row * epi.ldo + nbp;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(xr + 16 * j);
+                    acc[i][j] = f32x4{x4.x, x4.y, x4.z, x4.w};
+                }
+            }
+        }
+        if (epi.bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 b4 = *reinterpret_cast<const float4*>(epi.bias + nbp + 16 * j);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
+                }
+            }
+        }
+        if (epi.alpha != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] *= ia;
+        }
+        // (the compiler's own wait for these loads lands here, before the K loop: without the empty asm it would sit in front of the
+        // first MFMA of every accumulator, i.e. between the direct-to-LDS pieces of the first K step, as vmcnt(0))
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]));
+    } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if constexpr (PIPE) {
         // Software-pipelined K loop (BK = 64, two LDS stages, two fragment register sets).  One K step of a wave:
         //   phase 1   MI groups of 4 MFMAs on the step's first K half (set A), the reads of its second half (set B) between them
@@ -288,10 +365,47 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         }                                                                                          \
     } while (0)
         if (first_tile) GEMM_PROLOGUE();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // fp16 epilogues: the 2 * MI stores of the previous (full) tile were issued AFTER this tile's first pieces, so "at most 2 * MI
+        // operations outstanding" already means the pieces have landed (vmcnt retires in issue order): the stores drain under the first K
+        // step instead of in front of it (a raw barrier: __syncthreads() would add its own vmcnt(0) while LDS-DMA is pending)
+        if (PAIR && stores_pending) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * MI) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         GEMM_STAMP(1);
+        if (IBL_GEMM_TOUCH && tile + (int)gridDim.x < nwg) {     // issued here, behind the tile-top wait and before the fragments exist:
+                                                                 // the K loop has no register to spare (two more live VGPRs spill its LDS addresses)
+            int _bid = tile + (int)gridDim.x;
+            const int _q = nwg / 8, _r = nwg % 8, _xcd = _bid % 8;
+            _bid = (_xcd < _r ? _xcd * (_q + 1) : _r * (_q + 1) + (_xcd - _r) * _q) + _bid / 8;
+            const int prow0 = (_bid / nbn) * BM, pcol0 = (_bid % nbn) * BN;
+            // (32-bit arithmetic on a freshly formed lane id: the K loop has no register to spare -- two more live VGPRs spill its
+            // LDS fragment addresses)
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const bool act = wv < NW / 2;
+            const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            unsigned r = (unsigned)((act ? prow0 : pcol0) + (wv % (NW / 2)) * 64) + ln;
+            if (act) r = r < (unsigned)M ? r : (unsigned)(M - 1);
+            const unsigned touch_off = r * (unsigned)((act ? lda : ldw) * 2);
+            const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(act ? A : W), 0, -1, 0x00020000);
+            unsigned char* const tdst = smem + NS * STAGE + wave * 512;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (__attribute__((address_space(3))) void*)tdst, 4, touch_off, 0, 0, 0);
+            if (nk > 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (__attribute__((address_space(3))) void*)(tdst + 256), 4, touch_off, BK * 2, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         h16x8 afA[MI], wfA[4], afB[MI], wfB[4];
+        // L2 touches for the NEXT tile of this block (round 4).  Per-tile stamps: from the request of a tile's first two operand stages to the
+        // start of its K loop pass ~14 k clocks whatever the epilogue in between does (shortening the fp16 epilogue by 1.5 k lengthened the
+        // wait at the tile top by 1.5 k; 32 instead of 256 active CUs change nothing): the 112 KB are first touches of a new row panel,
+        // L2 misses, and a CU sustains ~8.5 B / clock of those.  So the lines of those two stages are requested one tile EARLY, as 4-byte
+        // direct-to-LDS loads into a scratch area (no VGPR, no use of the data): one per lane and stage, waves 0 .. NW / 2 - 1 the rows of
+        // the activation tile, the others the rows of the weight tile; the pieces issued at the end of this tile then hit L2.
+        // (the offsets are formed where the touches are issued: nothing of this lives across the K loop)
 #pragma unroll
         for (int j = 0; j < 4; ++j) wfA[j] = FRAG_W(0, 0, j);
 #pragma unroll
@@ -410,6 +524,25 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     // the tile this block computes next: its first stage is requested now (both LDS buffers are free: every wave's last LDS read
     // returned before the barrier of the final K step)
     const int erow0 = row0, ecol0 = col0;
+    // fp16 epilogues: this lane's 16 bias values are fetched -- and waited for -- BEFORE the next tile's direct-to-LDS pieces are issued.
+    // Round 4 (per-tile stamps, tools/perf_gemm.py --stamps): "prologue of the next tile + epilogue" took 12.9 k of a qkv tile's 51 k
+    // clocks although it stores 128 KB.  The bias loads used to follow the pieces, and with LDS-DMA pieces in flight the compiler waits
+    // vmcnt(0) at every use of an ordinary load's result -- in each of the eight per-row-group blocks (`if (row >= M) continue`), i.e.
+    // also for the previous group's STORES to complete: eight exposed store latencies per tile.  Now: bias first (the empty asm consumes
+    // the registers, so the compiler's wait sits here, with nothing else outstanding), then the pieces, then branch-free stores.
+    float bb[2][8];
+    if constexpr (PAIR) {
+        const int nbp = ecol0 + wn * 64 + 8 * fg;
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 b4 = epi.bias ? *reinterpret_cast<const float4*>(epi.bias + nbp + 32 * j2 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bb[j2][4 * h] = b4.x; bb[j2][4 * h + 1] = b4.y; bb[j2][4 * h + 2] = b4.z; bb[j2][4 * h + 3] = b4.w;
+            }
+        asm volatile("" ::"v"(bb[0][0]), "v"(bb[0][1]), "v"(bb[0][2]), "v"(bb[0][3]), "v"(bb[0][4]), "v"(bb[0][5]), "v"(bb[0][6]), "v"(bb[0][7]),
+                     "v"(bb[1][0]), "v"(bb[1][1]), "v"(bb[1][2]), "v"(bb[1][3]), "v"(bb[1][4]), "v"(bb[1][5]), "v"(bb[1][6]), "v"(bb[1][7]));
+    }
     tile += gridDim.x;
     const bool has_next = PIPE && tile < nwg;
     if constexpr (PIPE) {
@@ -421,11 +554,36 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
 
 
     // epilogue.  D layout: col = lane & 15 -> output row m; MFMA row 4*fg + r of n-tile j -> output column 16*fg + 4*j + r
-    if (NAT) {
+    if (PRE) {
+        // the accumulators hold (x + bias) / alpha + a W^T: 32 plain stores
+        const int nb = ecol0 + wn * 64 + 4 * fg;
+        const float al = epi.alpha;
+        if (erow0 + BM <= M) {
+            float* const obase = reinterpret_cast<float*>(epi.out) + (int64_t)(erow0 + wm * (MI * 16) + fr) * epi.ldo + nb;
+            const int64_t gstride = 16 * epi.ldo;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(obase + i * gstride + 16 * j) =
+                        make_float4(acc[i][j][0] * al, acc[i][j][1] * al, acc[i][j][2] * al, acc[i][j][3] * al);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
+                if (row >= M) continue;
+                float* orow = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + nb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(orow + 16 * j) = make_float4(acc[i][j][0] * al, acc[i][j][1] * al, acc[i][j][2] * al, acc[i][j][3] * al);
+            }
+        }
+    } else if (NAT) {
         // x[row][n] += scale[n] * (acc + bias[n]); lane (fr, fg) owns columns 16 j + 4 fg + 0..3 of n-tile j
         const int nb = ecol0 + wn * 64 + 4 * fg;
-#ifndef IBL_GEMM_EPI_SERIAL
-        // Round 4.  The read-modify-write used to run as eight dependent rounds (4 loads, wait, 4 stores per 16-row group -- and vmcnt counts
+#ifdef IBL_GEMM_EPI_BATCHED
+        // Round 4 (lab switch, measured SLOWER: proj 131 -> 147 us, fc2 298 -> 313 us -- the compiler folds the additions into the
+        // accumulators and keeps three loads in flight whatever the source order; 16 + 16 spills).  The read-modify-write used to run as eight dependent rounds (4 loads, wait, 4 stores per 16-row group -- and vmcnt counts
         // stores too on gfx9, so every round also waited for the previous round's stores): ~16 exposed memory latencies, 34 k clocks per tile
         // at K = 768 where the whole K loop is 35 k.  Now: the increments are formed in place in the accumulators (bias / scale registers
         // die), then the 32 float4 of the residual tile are requested in three batches (12 + 12 + 8) with two batches always in flight,
@@ -514,34 +672,35 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
 #endif
     } else if (PAIR) {
         const int nb = ecol0 + wn * 64 + 8 * fg;
-        float bb[2][8];
+#define PAIR_STORE(I, OROW)                                                                                                         \
+        _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2) {                                                                          \
+            float v[8];                                                                                                             \
+            _Pragma("unroll") for (int t = 0; t < 8; t += 2) {                                                                      \
+                f32x2 x = {acc[I][2 * j2 + (t >> 2)][t & 3], acc[I][2 * j2 + (t >> 2)][(t & 3) + 1]};                               \
+                x += f32x2{bb[j2][t], bb[j2][t + 1]};                                                                               \
+                if (EPI == EPI_BIAS_GELU_H16) x = gelu_erf2(x);                                                                     \
+                v[t] = x.x; v[t + 1] = x.y;                                                                                         \
+            }                                                                                                                       \
+            *reinterpret_cast<uint4*>((OROW) + 32 * j2) =                                                                           \
+                make_uint4(f2h_pk(v[0], v[1]), f2h_pk(v[2], v[3]), f2h_pk(v[4], v[5]), f2h_pk(v[6], v[7]));                         \
+        }
+        if (erow0 + BM <= M) {                 // full tile (all but the last row of tiles): no per-row branch between the stores
+            u16* const obase = reinterpret_cast<u16*>(epi.out) + (int64_t)(erow0 + wm * (MI * 16) + fr) * epi.ldo + nb;
+            const int64_t gstride = 16 * epi.ldo;
 #pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2)
+            for (int i = 0; i < MI; ++i) { PAIR_STORE(i, obase + i * gstride) }
+            stores_pending = true;
+        } else {
+            stores_pending = false;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 b4 = epi.bias ? *reinterpret_cast<const float4*>(epi.bias + nb + 32 * j2 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bb[j2][4 * h] = b4.x; bb[j2][4 * h + 1] = b4.y; bb[j2][4 * h + 2] = b4.z; bb[j2][4 * h + 3] = b4.w;
-            }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
-            if (row >= M) continue;
-            u16* orow = reinterpret_cast<u16*>(epi.out) + (int64_t)row * epi.ldo + nb;
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {
-                float v[8];
-#pragma unroll
-                for (int t = 0; t < 8; t += 2) {
-                    f32x2 x = {acc[i][2 * j2 + (t >> 2)][t & 3], acc[i][2 * j2 + (t >> 2)][(t & 3) + 1]};
-                    x += f32x2{bb[j2][t], bb[j2][t + 1]};
-                    if (EPI == EPI_BIAS_GELU_H16) x = gelu_erf2(x);
-                    v[t] = x.x; v[t + 1] = x.y;
-                }
-                *reinterpret_cast<uint4*>(orow + 32 * j2) =
-                    make_uint4((unsigned)f2h(v[0]) | ((unsigned)f2h(v[1]) << 16), (unsigned)f2h(v[2]) | ((unsigned)f2h(v[3]) << 16),
-                               (unsigned)f2h(v[4]) | ((unsigned)f2h(v[5]) << 16), (unsigned)f2h(v[6]) | ((unsigned)f2h(v[7]) << 16));
+            for (int i = 0; i < MI; ++i) {
+                const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
+                if (row >= M) continue;
+                u16* orow = reinterpret_cast<u16*>(epi.out) + (int64_t)row * epi.ldo + nb;
+                PAIR_STORE(i, orow)
             }
         }
+#undef PAIR_STORE
     } else {
     const int n0 = ecol0 + wn * 64 + 16 * fg;          // first of this lane's 16 consecutive columns
     float bias[16], scale[16];
@@ -630,7 +789,7 @@ template <int EPI, int MI, int WM, int WN, int BK, int OCC, int NS, bool PIPE = 
 static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw, int M, int N, int K, const GemmEpi& epi, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     const int nwg = (N / BN) * ((M + BM - 1) / BM);
-    const size_t lds = NS * (size_t)(BM + BN) * BK * 2;
+    const size_t lds = NS * (size_t)(BM + BN) * BK * 2 + (PIPE ? (size_t)WM * WN * 512 : 0);     // (+ the landing area of the L2 touches, 512 B per wave)
     // the dynamic-LDS limit is a per-device property of the function: set once per device of this process.  The bit mask is only
     // a cache -- two threads racing here both set the same value (localise_concurrent lanes launch from several host threads)
     static std::atomic<unsigned long long> attr_set{0};
@@ -655,9 +814,12 @@ static int launch_gemm_cfg(const u16* A, int64_t lda, const u16* W, int64_t ldw,
             n_cu.store(cus, std::memory_order_relaxed);
         }
         if (grid > cus * OCC) grid = cus * OCC;
+        static int cap = -2;                 // lab: IBL_GEMM_MAXGRID caps the persistent grid (is a per-tile phase bound by the chip or by the CU?)
+        if (cap == -2) { const char* e = getenv("IBL_GEMM_MAXGRID"); cap = e ? atoi(e) : 0; }
+        if (cap > 0 && grid > cap) grid = cap;
     }
     GemmEpi e2 = epi;
-    if (PIPE && EPI == EPI_RESID_F32 && grid < nwg) {
+    if (PIPE && grid < nwg) {
         // lab only (IBL_GEMM_STAGGER = s_sleep(64) units per phase group): measured and rejected in round 3 -- proj 125 / 142 / 155 / 171 us
         // and fc2 304 / 311 / 322 / 341 us at 0 / 3 / 6 / 10: the epilogue is not slowed by the other workgroups' epilogues, the delay is
         // pure tail
@@ -688,6 +850,17 @@ static int gemm_cfg_override() {
         v = e ? atoi(e) : -1;
     }
     return v;
+}
+
+// EPI_RESID_PRE_F32 (residual tile preloaded into the accumulators, store-only epilogue) is a lab switch: measured per tile with
+// tools/perf_gemm.py --stamps, the preload of the 256 KB tile at the tile top costs what the read-modify-write behind the K loop costs
+// (30 k vs 38 - 12 k clocks: a CU sustains ~8.5 B / clock of L2-missing loads whatever their arrangement, and the count does not change
+// with 32 instead of 256 active CUs), end to end proj 131 -> 138 us, fc2 298 -> 309 us.  IBL_GEMM_RESID_PRE=1 selects it where no scale
+// vector is given.
+static bool gemm_resid_pre() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IBL_GEMM_RESID_PRE"); v = (e && atoi(e)) ? 1 : 0; }
+    return v == 1;
 }
 
 template <int EPI>
@@ -986,7 +1159,9 @@ extern "C" int ibl_linear_f16(const void* x, int64_t ldx, const void* W, int64_t
     switch (epilogue) {
         case EPI_BIAS_H16: return launch_gemm<EPI_BIAS_H16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
         case EPI_BIAS_GELU_H16: return launch_gemm<EPI_BIAS_GELU_H16>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
-        case EPI_RESID_F32: return launch_gemm<EPI_RESID_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
+        case EPI_RESID_F32:
+            if (!e.scale && gemm_resid_pre()) { e.alpha = 1.0f; return launch_gemm<EPI_RESID_PRE_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s); }
+            return launch_gemm<EPI_RESID_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
         case EPI_BIAS_F32: return launch_gemm<EPI_BIAS_F32>(a, ldx, w, ldw, (int)rows, n_out, n_in, e, s);
         default: return ibl_set_error(IBL_ERR_ARG, "ibl_linear_f16: unknown epilogue %d", epilogue);
     }
@@ -1126,13 +1301,17 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
         if (st) return st;
         {
             GemmEpi e{};
-            e.bias = L->b_o; e.scale = L->ls1; e.out = x; e.ldo = cls_only ? TD : D;
-            st = launch_gemm<EPI_RESID_F32>(att, cls_only ? TD : D, reinterpret_cast<const u16*>(L->w_o), D, cls_only ? batch : (int)Rn, D, D,
-                                            e, s);
+            e.bias = L->b_o; e.scale = L->ls1; e.out = x; e.ldo = cls_only ? TD : D; e.alpha = 1.0f;
+            // no LayerScale vector (none in the model, or folded into W_o / b_o by the host): the residual tile is preloaded into the
+            // accumulators (EPI_RESID_PRE_F32); with one, the read-modify-write epilogue applies it
+            st = (L->ls1 || !gemm_resid_pre()) ? launch_gemm<EPI_RESID_F32>(att, cls_only ? TD : D, reinterpret_cast<const u16*>(L->w_o), D, cls_only ? batch : (int)Rn, D, D, e, s)
+                        : launch_gemm<EPI_RESID_PRE_F32>(att, cls_only ? TD : D, reinterpret_cast<const u16*>(L->w_o), D, cls_only ? batch : (int)Rn, D, D, e, s);
             if (st) return st;
-            if (!cls_only && L->w_o_lo && L->ls1_lo) {       // second weight term: x += (ls1 / S) * (att W_lo'^T)
-                e.bias = nullptr; e.scale = L->ls1_lo; e.algo_k = -1;
-                st = launch_gemm<EPI_RESID_F32>(att, D, reinterpret_cast<const u16*>(L->w_o_lo), D, (int)Rn, D, D, e, s);
+            if (!cls_only && L->w_o_lo) {                    // second weight term: x += (ls1 / S) * (att W_lo'^T); without a vector x += (att W_lo'^T) / S
+                                                             // (the preloading kernel: it carries the power-of-two factor)
+                e.bias = nullptr; e.scale = L->ls1_lo; e.algo_k = -1; e.alpha = 1.0f / IBL_VIT_SPLIT_SCALE;
+                st = L->ls1_lo ? launch_gemm<EPI_RESID_F32>(att, D, reinterpret_cast<const u16*>(L->w_o_lo), D, (int)Rn, D, D, e, s)
+                               : launch_gemm<EPI_RESID_PRE_F32>(att, D, reinterpret_cast<const u16*>(L->w_o_lo), D, (int)Rn, D, D, e, s);
                 if (st) return st;
             }
         }
@@ -1156,12 +1335,14 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
         }
         {
             GemmEpi e{};
-            e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = cls_only ? TD : D;
-            st = launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
+            e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = cls_only ? TD : D; e.alpha = 1.0f;
+            st = (L->ls2 || !gemm_resid_pre()) ? launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s)
+                        : launch_gemm<EPI_RESID_PRE_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
             if (st) return st;
-            if (!cls_only && L->w_fc2_lo && L->ls2_lo) {
-                e.bias = nullptr; e.scale = L->ls2_lo; e.algo_k = -1;
-                st = launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2_lo), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
+            if (!cls_only && L->w_fc2_lo) {
+                e.bias = nullptr; e.scale = L->ls2_lo; e.algo_k = -1; e.alpha = 1.0f / IBL_VIT_SPLIT_SCALE;
+                st = L->ls2_lo ? launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2_lo), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s)
+                               : launch_gemm<EPI_RESID_PRE_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2_lo), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
                 if (st) return st;
             }
         }

@@ -30,12 +30,10 @@ BILINEAR = "bilinear"
 def _bicubic_filter(x):
     a = -0.5
     x = np.abs(x)
-    out = np.zeros_like(x)
-    m1 = x < 1.0
-    m2 = (x >= 1.0) & (x < 2.0)
-    out[m1] = ((a + 2.0) * x[m1] - (a + 3.0)) * x[m1] * x[m1] + 1
-    out[m2] = (((x[m2] - 5) * x[m2] + 8) * x[m2] - 4) * a
-    return out
+    # (both polynomials on every element, then a select: same float64 values as the masked assignment, several times faster)
+    p1 = ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    p2 = (((x - 5) * x + 8) * x - 4) * a
+    return np.where(x < 1.0, p1, np.where(x < 2.0, p2, 0.0))
 
 
 def _bilinear_filter(x):
@@ -131,6 +129,47 @@ class CropDesc(C.Structure):
 _TABLES = {}            # (in_size, out_size, filter, window) -> (records, ksize): crop sizes recur from batch to batch
 
 
+def resample_tables(keys):
+    """`resample_table` for many (in_size, out_size, filt, win0, win_n) keys in one vectorised pass per (filter, window length): the
+    tables of a batch of differently sized crops (two per crop) cost one numpy expression instead of one per table.  Same float64
+    arithmetic per sample (rows are padded to the widest support of the group; padding taps are masked out before the sum)."""
+    out = {}
+    groups = {}
+    for key in keys:
+        groups.setdefault((key[2], key[4]), []).append(key)
+    for (filt, win_n), ks in groups.items():
+        fn, fsupport = _FILTERS[filt]
+        in_size = np.array([k[0] for k in ks], dtype=np.float64)[:, None]
+        out_size = np.array([k[1] for k in ks], dtype=np.float64)[:, None]
+        win0 = np.array([k[3] for k in ks], dtype=np.float64)[:, None]
+        scale = in_size / out_size
+        filterscale = np.where(scale >= 1.0, scale, 1.0)
+        support = fsupport * filterscale
+        ksize = np.ceil(support).astype(np.int64)[:, 0] * 2 + 1
+        kmax = int(ksize.max())
+        ss = 1.0 / filterscale
+        center = (win0 + np.arange(win_n, dtype=np.float64)[None, :] + 0.5) * scale            # [T][win_n]
+        xmin = (center - support + 0.5).astype(np.int64)
+        xmin[xmin < 0] = 0
+        xmax = (center + support + 0.5).astype(np.int64)
+        xmax = np.minimum(xmax, in_size.astype(np.int64))
+        xmax -= xmin
+        xs = np.arange(kmax, dtype=np.float64)[None, None, :]
+        taps = xs < xmax[:, :, None]
+        w = fn((xs + xmin[:, :, None] - center[:, :, None] + 0.5) * ss[:, :, None]) * taps
+        ww = np.add.accumulate(w, axis=2)[:, :, -1]
+        w = np.where((ww != 0.0)[:, :, None], w / np.where(ww != 0.0, ww, 1.0)[:, :, None], w)
+        k = np.where(w < 0, (-0.5 + w * (1 << PRECISION_BITS)).astype(np.int64), (0.5 + w * (1 << PRECISION_BITS)).astype(np.int64))
+        k = np.where(taps, k, 0)
+        for t, key in enumerate(ks):
+            rec = np.zeros((win_n, 2 + int(ksize[t])), dtype=np.int32)
+            rec[:, 0] = xmin[t]
+            rec[:, 1] = xmax[t]
+            rec[:, 2:] = k[t, :, :int(ksize[t])]
+            out[key] = (rec, int(ksize[t]))
+    return out
+
+
 def _cached_table(in_size, out_size, filt, win0, win_n):
     key = (in_size, out_size, filt, win0, win_n)
     t = _TABLES.get(key)
@@ -172,6 +211,18 @@ class TableCache:
 def plan_batch(recipe: PreprocessRecipe, shapes):
     """shapes: list of (H, W).  Returns (descs ndarray of CropDesc, tables int32, src_bytes, tmp_bytes, max_h)."""
     cache = TableCache()
+    # every table the batch needs and the process has not built yet, in one vectorised pass
+    want = set()
+    for (h, w) in shapes:
+        rh, rw, top, left = resized_size(recipe, h, w)
+        for key in ((w, rw, recipe.filt, left, recipe.out_w), (h, rh, recipe.filt, top, recipe.out_h)):
+            if key[0] != key[1] and key not in _TABLES:
+                want.add(key)
+    if want:
+        built = resample_tables(sorted(want))
+        if len(_TABLES) + len(built) > 8192:
+            _TABLES.clear()
+        _TABLES.update(built)
     descs = (CropDesc * len(shapes))()
     src_off = 0
     tmp_off = 0

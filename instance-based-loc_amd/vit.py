@@ -242,13 +242,17 @@ class PackedCrops:
 class VitEncoder:
     """Device-resident weights + batched forward through the C-ABI."""
 
-    def __init__(self, cfg: VitConfig, weights: dict, device="cuda", precision=None):
-        """precision: operand-term plan (see DEFAULT_PRECISION; None = $IBL_VIT_PREC or the default, "plain" = fp16 operands only)"""
+    def __init__(self, cfg: VitConfig, weights: dict, device="cuda", precision=None, fold_layerscale=None):
+        """precision: operand-term plan (see DEFAULT_PRECISION; None = $IBL_VIT_PREC or the default, "plain" = fp16 operands only);
+        fold_layerscale: LayerScale multiplied into the output-projection weights at load, so that the library may run the residual GEMMs
+        with the residual tile preloaded (lab: with IBL_GEMM_RESID_PRE=1; measured 2 % slower than the read-modify-write epilogue, so the
+        default -- also with $IBL_VIT_FOLD_LS unset -- keeps the LayerScale vectors and round 3's arithmetic)"""
         if cfg.depth > MAX_LAYERS:
             raise ValueError("too many layers")
         import os
         self.precision = precision if precision is not None else os.environ.get("IBL_VIT_PREC", DEFAULT_PRECISION)
         patch_terms, layer_terms = parse_precision(self.precision)
+        self.fold_layerscale = (os.environ.get("IBL_VIT_FOLD_LS", "0") == "1") if fold_layerscale is None else bool(fold_layerscale)
         self.cfg = cfg
         self.device = torch.device(device)
         self._keep = []                     # device tensors referenced by the structs
@@ -287,11 +291,19 @@ class VitEncoder:
             L.ln1_g, L.ln1_b = dev_f32(weights[p + "ln1.g"]), dev_f32(weights[p + "ln1.b"])
             L.w_qkv = dev_f16(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0))
             L.b_qkv = dev_f32(np.concatenate([weights[p + "q.b"], weights[p + "k.b"], weights[p + "v.b"]], axis=0))
-            L.w_o, L.b_o = dev_f16(weights[p + "o.w"]), dev_f32(weights[p + "o.b"])
+            # fold_layerscale (lab, off by default): x += ls * (a W^T + b) = a (diag(ls) W)^T + ls * b.  Without a scale vector in the
+            # epilogue the library can preload the residual tile into the accumulators (EPI_RESID_PRE_F32, csrc/vit.hip).
+            w_o, b_o, w_fc2, b_fc2 = weights[p + "o.w"], weights[p + "o.b"], weights[p + "fc2.w"], weights[p + "fc2.b"]
+            fold = self.fold_layerscale              # (without LayerScale: "folded" = no 1 / S vectors for the second terms either)
+            if fold and cfg.layerscale:
+                ls1, ls2 = np.asarray(weights[p + "ls1"], np.float32), np.asarray(weights[p + "ls2"], np.float32)
+                w_o, b_o = ls1[:, None] * np.asarray(w_o, np.float32), ls1 * np.asarray(b_o, np.float32)
+                w_fc2, b_fc2 = ls2[:, None] * np.asarray(w_fc2, np.float32), ls2 * np.asarray(b_fc2, np.float32)
+            L.w_o, L.b_o = dev_f16(w_o), dev_f32(b_o)
             L.ln2_g, L.ln2_b = dev_f32(weights[p + "ln2.g"]), dev_f32(weights[p + "ln2.b"])
             L.w_fc1, L.b_fc1 = dev_f16(weights[p + "fc1.w"]), dev_f32(weights[p + "fc1.b"])
-            L.w_fc2, L.b_fc2 = dev_f16(weights[p + "fc2.w"]), dev_f32(weights[p + "fc2.b"])
-            if cfg.layerscale:
+            L.w_fc2, L.b_fc2 = dev_f16(w_fc2), dev_f32(b_fc2)
+            if cfg.layerscale and not fold:
                 L.ls1, L.ls2 = dev_f32(weights[p + "ls1"]), dev_f32(weights[p + "ls2"])
             nrun_ = cfg.depth if cfg.n_blocks_run < 0 else cfg.n_blocks_run
             if (l in layer_terms or "*" in layer_terms) and not (l == nrun_ - 1 and not cfg.out_all_tokens):     # the CLS-only last block stays plain
@@ -301,14 +313,16 @@ class VitEncoder:
                     L.w_qkv_x = dev_f16(split_terms(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0), tq))
                     L.qkv_terms = tq
                 if to > 1:
-                    L.w_o_lo = dev_f16(weight_lo(weights[p + "o.w"]))
-                    L.ls1_lo = dev_f32((weights[p + "ls1"] if cfg.layerscale else ones) / SPLIT_SCALE)
+                    L.w_o_lo = dev_f16(weight_lo(w_o))
+                    if not fold:                             # (no vector: the library adds the term with the factor 1 / S, residual preloaded)
+                        L.ls1_lo = dev_f32((weights[p + "ls1"] if cfg.layerscale else ones) / SPLIT_SCALE)
                 if t1 > 1:
                     L.w_fc1_x = dev_f16(split_terms(weights[p + "fc1.w"], t1))
                     L.fc1_terms = t1
                 if t2 > 1:
-                    L.w_fc2_lo = dev_f16(weight_lo(weights[p + "fc2.w"]))
-                    L.ls2_lo = dev_f32((weights[p + "ls2"] if cfg.layerscale else ones) / SPLIT_SCALE)
+                    L.w_fc2_lo = dev_f16(weight_lo(w_fc2))
+                    if not fold:
+                        L.ls2_lo = dev_f32((weights[p + "ls2"] if cfg.layerscale else ones) / SPLIT_SCALE)
         self.W = W
         flags = 0
         flags |= FLAG_LAYERSCALE if cfg.layerscale else 0
