@@ -152,6 +152,16 @@ extern "C" int ibl_gemm_stamps_clear() {
 #define GEMM_STAMP(k)
 #endif
 
+#ifdef IBL_GEMM_NOMFMA             // lab: the K loop without its MFMAs -- how fast does a CU stream the operand stages into LDS?
+#define IBL_MFMA(a, b, c, x, y, z) (c)
+#else
+#define IBL_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#endif
+#ifndef IBL_GEMM_L2AHEAD
+#define IBL_GEMM_L2AHEAD 0          // lab (-DIBL_GEMM_L2AHEAD=D): every workgroup requests its share of the activation panel's lines of K step
+                                    // kt + D into L2.  Measured per ViT-B layer: 1 034 us off, 1 073 / 1 089 / 1 088 us at D = 2 / 3 / 4 --
+                                    // the operand stream is not slow because it misses L2
+#endif
 #ifndef IBL_GEMM_TOUCH
 #define IBL_GEMM_TOUCH 0            // lab (-DIBL_GEMM_TOUCH=1): L2 touches of the next tile's first stages, one tile early.  Measured: the wait
                                     // at the tile top 6.2 -> 4.9 k clocks, but the K step that carries the touches waits for them (K loop
@@ -398,6 +408,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (__attribute__((address_space(3))) void*)(tdst + 256), 4, touch_off, BK * 2, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if IBL_GEMM_L2AHEAD > 0
+        // (wave-uniform: SGPRs) which quarter(s) of the row panel this workgroup requests ahead; not on the last row of tiles (rows beyond M)
+        const bool l2ahead = row0 + BM <= M && nk > IBL_GEMM_L2AHEAD;
+        const int tcol = col0 / BN;
+        const bool l2two = nbn < 4;
+        const unsigned touch_row0 = (unsigned)((tcol & 3) * 64 * lda * 2);
+        const unsigned touch_row1 = (unsigned)(((tcol + nbn) & 3) * 64 * lda * 2);
+#endif
         h16x8 afA[MI], wfA[4], afB[MI], wfB[4];
         // L2 touches for the NEXT tile of this block (round 4).  Per-tile stamps: from the request of a tile's first two operand stages to the
         // start of its K loop pass ~14 k clocks whatever the epilogue in between does (shortening the fp16 epilogue by 1.5 k lengthened the
@@ -417,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
 #pragma unroll
             for (int g = 0; g < MI; ++g) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfA[j], afA[g], acc[g][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[g][j] = IBL_MFMA(wfA[j], afA[g], acc[g][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);         // reads after the group: the wait before it then covers set A only
 #pragma unroll
                 for (int t = g * LB; t < (g + 1) * LB && t < NL; ++t) {
@@ -431,11 +449,36 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
 #pragma unroll
             for (int g = 0; g < HA; ++g) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfB[j], afB[g], acc[g][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[g][j] = IBL_MFMA(wfB[j], afB[g], acc[g][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+#if IBL_GEMM_L2AHEAD > 0
+            // Cooperative L2 prefetch of the activation panel (round 4).  The K loop takes the same ~3 000 clocks per step WITHOUT its MFMAs
+            // (lab build -DIBL_GEMM_NOMFMA): it is bound by how fast a CU streams its 64 KB of operands into LDS, and the tiles that find
+            // their panel in L2 run at 1 300 clocks per step.  The nbn column tiles of a row panel run side by side on one XCD and all miss
+            // on the same activation lines at the same time.  So every workgroup requests a QUARTER of its row panel's lines of K step
+            // kt + IBL_GEMM_L2AHEAD now (4-byte direct-to-LDS loads into a scratch area: the offsets of piece 0 cover 64 rows, the quarter is
+            // chosen by the tile's column), as the LAST memory operation of the step: the wait below then lets exactly that one stay in
+            // flight (vmcnt retires in order), and it is the oldest operation when the next step waits.
+            if (l2ahead && kt + IBL_GEMM_L2AHEAD < nk) {
+                const unsigned ko2 = (unsigned)((kt + IBL_GEMM_L2AHEAD) * BK * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(smem + NS * STAGE + wave * 512), 4, a_off[0],
+                                                         touch_row0 + ko2, 0, 0);
+                if (l2two) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(smem + NS * STAGE + wave * 512 + 256), 4,
+                                                             a_off[0], touch_row1 + ko2, 0, 0);
+                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+#else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces have landed, its set-B reads have returned
             __syncthreads();
+#endif
             // ---- phase 2b
             const int nb = buf ^ 1;
 #pragma unroll
@@ -448,7 +491,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[HA + g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfB[j], afB[HA + g], acc[HA + g][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[HA + g][j] = IBL_MFMA(wfB[j], afB[HA + g], acc[HA + g][j], 0, 0, 0);
                 if (more2) GEMM_SLOT(g, kt + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -490,7 +533,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = IBL_MFMA(wf[j], af[i], acc[i][j], 0, 0, 0);
                 const int g = ks * MI + i;
 #pragma unroll
                 // pieces are issued over the first half of the step's groups: one issued in the last groups has not landed at the
@@ -1061,8 +1104,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
             const h16x8 k0 = *reinterpret_cast<const h16x8*>(kp);
             const h16x8 k1 = *reinterpret_cast<const h16x8*>(kp + 64);
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf0, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf1, a, 0, 0, 0);
+            a = IBL_MFMA(k0, qf0, a, 0, 0, 0);
+            a = IBL_MFMA(k1, qf1, a, 0, 0, 0);
             // raw scores: the softmax scale is folded into the exponent below (scale > 0: the maximum commutes); only a tile that
             // reaches past T needs the key mask (the softmax arithmetic, not the MFMAs, bounds this kernel: ~10 VALU per score before)
             if (t * 16 + 16 > T) {
@@ -1114,7 +1157,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
                 if (2 * s + 1 < NT) hi = *reinterpret_cast<const uint2*>(vp + 32);
                 uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 const h16x8 vf = *reinterpret_cast<const h16x8*>(&packed);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);     // O^T tile: rows = d, columns = q
+                o[dt] = IBL_MFMA(vf, pf, o[dt], 0, 0, 0);     // O^T tile: rows = d, columns = q
             }
             asm volatile("" ::: "memory");
         }
