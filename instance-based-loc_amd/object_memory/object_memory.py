@@ -439,4 +439,50 @@ class ObjectMemory():
         res = self.localise_detections(embs, clouds, outlier_removal_config, fpfh_global_dist_factor, fpfh_local_dist_factor,
                                        fpfh_voxel_size, max_detected_object_num)
         last = res.assignments[-1] if res.assignments else []
+        if save_point_clouds and res.records:
+            self._save_registration_dumps(res, clouds, det_pts, det_cols, mem_pts, mem_cols, outlier_removal_config, max_detected_object_num,
+                                          subsave_root, image_path)
         return res.pose, [last, None]                                                 # :1169 (assn of the last loop iteration)
+
+    def _save_registration_dumps(self, res, clouds, det_pts, det_cols, mem_pts, mem_cols, outlier_cfg, max_det, subsave_root, image_path):
+        """The debugging artefacts of localise(save_point_clouds=True) after the registrations (object_memory.py:1092-1093, 1142-1165):
+        per assignment `only_chosen_<assn>.ply` = the chosen memory clouds + the chosen (cleaned) detected clouds moved by the
+        assignment's transform, both centred as the registration saw them; `_best_full_pcd<assn>.ply` = the whole memory (green) + all
+        detections (red, outlier-filtered once more) moved by the best transform, centred with the means of the LAST assignment (the
+        stale means of :1127, App. B); and a copy of the query image.  Host-side file writing, outside the hot path."""
+        import shutil
+        from .object_info import write_ply
+        # the detections in the order and cleaned state the registration used (:900-908, :992-998)
+        if isinstance(clouds, CloudBatch):
+            off = clouds.seg_off_host
+            dets = [(det_pts[0][off[i]:off[i + 1]], det_cols[0][off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+        else:
+            dets = list(zip(det_pts, det_cols))
+        if len(dets) > max_det:
+            dets = [dets[i] for i in sorted(range(len(dets)), key=lambda i: len(dets[i][0]), reverse=True)[:max_det]]
+        keep = radius_outlier_batch(self._ctx, CloudBatch.from_numpy([d[0] for d in dets], device=self.device), outlier_cfg["radius"],
+                                    outlier_cfg["radius_nb_points"]).bool().cpu().numpy()
+        o = np.concatenate([[0], np.cumsum([len(d[0]) for d in dets])])
+        cleaned = [(d[0][keep[o[i]:o[i + 1]]], d[1][keep[o[i]:o[i + 1]]]) for i, d in enumerate(dets)]
+
+        def moved(points, T):
+            return points @ T[:3, :3].T + T[:3, 3]
+
+        for rec in res.records:
+            assn = rec["assn"]
+            dp = np.concatenate([cleaned[d][0] for d, m in assn]) - rec["detected_mean"]
+            dc = np.concatenate([cleaned[d][1] for d, m in assn])
+            mp = np.concatenate([mem_pts[m] for d, m in assn]) - rec["memory_mean"]
+            mc = np.concatenate([mem_cols[m] for d, m in assn])
+            write_ply(os.path.join(subsave_root, "only_chosen_" + str(assn) + ".ply"), np.concatenate([mp, moved(dp, rec["T"])]),
+                      np.concatenate([mc, dc]))
+        best, lastrec = res.records[res.best], res.records[-1]
+        all_det = np.concatenate([c[0] for c in cleaned]) - lastrec["detected_mean"]
+        all_mem = np.concatenate(mem_pts) - lastrec["memory_mean"]
+        k2 = radius_outlier_batch(self._ctx, CloudBatch.from_numpy([all_det], device=self.device), outlier_cfg["radius"],
+                                  outlier_cfg["radius_nb_points"]).bool().cpu().numpy()
+        green, red = np.tile([0.0, 1.0, 0.0], (len(all_mem), 1)), np.tile([1.0, 0.0, 0.0], (int(k2.sum()), 1))
+        write_ply(os.path.join(subsave_root, "_best_full_pcd" + str(best["assn"]) + ".ply"),
+                  np.concatenate([all_mem, moved(all_det[k2], best["T"])]), np.concatenate([green, red]))
+        if image_path is not None and os.path.exists(str(image_path)):
+            shutil.copy(str(image_path), os.path.join(subsave_root, "rgb_image." + str(image_path).split(".")[-1]))

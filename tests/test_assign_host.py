@@ -85,3 +85,35 @@ def test_simvolume_facade_matches_reference_main_case():
     sv = SimVolume(cs)
     sv.fast_construct_volume(3)
     assert sv.get_top_indices_from_subvolumes(3) == CASES[0]["expected"]
+
+
+def test_simvolume_facade_extra_methods_match_the_reference_module():
+    """sub-volumes of another size than min(Q, 3) and the methods localise() never calls (construct_volume, get_top_indices,
+    conv_coords_to_pairs, construct_volume_choose_e; similarity_volume.py:30-100, 169-209) against outputs of the reference's own module
+    (tests/golden/simvolume_extra_golden.json, tools/gen_golden_simvolume.py extra)"""
+    import json
+    import os
+    from ibloc_amd.utils.similarity_volume import SimVolume
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "simvolume_extra_golden.json")))["cases"]
+    for c in gold:
+        sims = np.array(c["sims"], dtype=np.float32)
+        sv = SimVolume(sims)
+        sv.fast_construct_volume(c["subvolume_size"])
+        assert sv.get_top_indices_from_subvolumes(3) == c["assignments"], (c["Q"], c["M"], c["subvolume_size"])
+        if c["Q"] < 2:
+            assert SimVolume(sims).construct_volume() is not None
+            continue
+        vol, rep = SimVolume(sims).construct_volume()
+        assert list(vol.shape) == c["volume_shape"] and vol.dtype == np.float16
+        assert int(np.isfinite(rep).sum()) == c["finite_cells"]
+        assert abs(float(vol.astype(np.float64).sum()) - c["volume_sum"]) < 1e-9
+        assert abs(float(rep[np.isfinite(rep)].astype(np.float64).sum()) - c["rep_finite_sum"]) < 1e-9
+        top = SimVolume(sims).get_top_indices(rep.copy(), 6)
+        assert [[[int(x) for x in cell], float(v)] for cell, v in top] == c["top6"]
+        pairs = SimVolume(sims).conv_coords_to_pairs(rep, top)
+        assert [[[[int(i), int(j)] for i, j in pr], float(v)] for pr, v in pairs] == c["top6_pairs"]
+        ce = SimVolume(sims).construct_volume_choose_e([c["Q"] - 1, 0])
+        assert [[float(x) for x in r] for r in ce] == c["choose_e_last_first"]
+    big = SimVolume(np.zeros((4, 3000), dtype=np.float32))
+    with pytest.raises(MemoryError):
+        big.construct_volume()

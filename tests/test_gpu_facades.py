@@ -1,4 +1,6 @@
 """-m gpu: the reference-shaped Python surface (utils.fpfh_register, utils.embeddings, ObjectMemory.localise)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -149,6 +151,19 @@ def test_object_memory_localise_with_stub_finder(tmp_path):
     pts, cols = read_ply(f"pcds/{tmp_path / 't'}/s7/_init_pcd_s7.ply")
     n_mem = sum(len(np.asarray(m.pointcloud.points)) for m in om.memory)
     assert len(pts) > n_mem and cols is not None and len(cols) == len(pts)
+    # ... and after the registrations (:1092-1093, 1142-1165): one only_chosen_<assn>.ply per assignment, the best full cloud (memory
+    # green, detections red) and a copy of the query image
+    import glob
+    d = f"pcds/{tmp_path / 't'}/s7"
+    chosen = glob.glob(os.path.join(glob.escape(d), "only_chosen_*.ply"))
+    assert len(chosen) >= 1 and os.path.exists(os.path.join(d, "rgb_image.png"))
+    p1, c1 = read_ply(os.path.join(d, "only_chosen_[[0, 1]].ply"))
+    n1 = len(np.asarray(om.memory[1].pointcloud.points))
+    assert len(p1) > n1 and abs(p1[:n1].mean(axis=0)).max() < 1e-6               # the memory side is centred on its own mean
+    best = glob.glob(os.path.join(glob.escape(d), "_best_full_pcd*.ply"))
+    assert len(best) == 1
+    pb, cb = read_ply(best[0])
+    assert len(pb) > n_mem and np.array_equal(cb[:n_mem], np.tile([0.0, 1.0, 0.0], (n_mem, 1))) and np.array_equal(cb[-1], [1.0, 0.0, 0.0])
 
 
 def test_object_memory_pickle_round_trip(tmp_path):

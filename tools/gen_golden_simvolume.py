@@ -111,5 +111,40 @@ def main():
     print("wrote", OUT, len(cases), "cases")
 
 
+def extra():
+    """The parts of SimVolume localise() does not use (sub-volumes of another size than min(Q, 3), construct_volume, get_top_indices,
+    conv_coords_to_pairs, construct_volume_choose_e): outputs of the reference's own module on small seeded matrices."""
+    import contextlib
+    import io
+    mod = load_reference()
+    rng = np.random.default_rng(77)
+    cases = []
+    for Q, M, size in ((4, 6, 2), (5, 5, 4), (3, 7, 2), (4, 5, 3), (2, 6, 2), (5, 6, 2), (1, 4, 1)):
+        sims = rng.uniform(-0.3, 1, size=(Q, M)).astype(np.float32)
+        with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+            a = mod.SimVolume(sims.copy())
+            a.fast_construct_volume(size)
+            assns = a.get_top_indices_from_subvolumes(3)
+            c = {"Q": Q, "M": M, "subvolume_size": size, "sims": [[float(x) for x in r] for r in sims],
+                 "assignments": [[[int(d), int(m)] for d, m in asg] for asg in assns]}
+            if Q >= 2:
+                vol, rep = mod.SimVolume(sims.copy()).construct_volume()
+                top = mod.SimVolume(sims.copy()).get_top_indices(rep.copy(), 6)
+                pairs = mod.SimVolume(sims.copy()).conv_coords_to_pairs(rep, top)
+                ce = mod.SimVolume(sims.copy()).construct_volume_choose_e([Q - 1, 0])
+                c.update({"volume_shape": list(vol.shape), "finite_cells": int(np.isfinite(rep).sum()),
+                          "volume_sum": float(vol.astype(np.float64).sum()), "rep_finite_sum": float(rep[np.isfinite(rep)].astype(np.float64).sum()),
+                          "top6": [[[int(x) for x in cell], float(v)] for cell, v in top],
+                          "top6_pairs": [[[[int(i), int(j)] for i, j in pr], float(v)] for pr, v in pairs],
+                          "choose_e_last_first": [[float(x) for x in r] for r in ce]})
+        cases.append(c)
+    out = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "simvolume_extra_golden.json")
+    json.dump({"generator": "tools/gen_golden_simvolume.py extra()", "cases": cases}, open(out, "w"))
+    print("wrote", out, len(cases), "cases")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra()
+    else:
+        main()

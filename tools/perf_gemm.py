@@ -15,12 +15,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ibloc_amd import vit as V
 
+PAD = int(os.environ.get("GEMM_PAD", "0"))          # elements added to the row stride of both operands (L2 channel spreading experiment)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 224 * 257
 shapes = [("qkv", 2304, 768, 0), ("proj", 768, 768, 2), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)]
 tot_ms, tot_fl = 0.0, 0.0
 for name, n_out, n_in, epi in shapes:
-    x = torch.randn(rows, n_in, device="cuda").to(torch.float16)
-    W = (torch.randn(n_out, n_in, device="cuda") / n_in ** 0.5).to(torch.float16)
+    x = torch.randn(rows, n_in + PAD, device="cuda").to(torch.float16)[:, :n_in]
+    W = (torch.randn(n_out, n_in + PAD, device="cuda") / n_in ** 0.5).to(torch.float16)[:, :n_in]
     b = torch.randn(n_out, device="cuda")
     out = torch.zeros(rows, n_out, device="cuda", dtype=torch.float32 if epi == 2 else torch.float16)
     for _ in range(3):
