@@ -8,6 +8,7 @@ clouds of every candidate assignment, whole-memory evaluation, on one MI355X.  `
     C2  DINOv2-B/14, M = 1 000          (BASELINE configs[1])
     C3  DATOR RGB-D dual stream (256x128 RGB + depth crops), M = 5 000, D = 128   (configs[2])
     C1  DINOv2-S/14 (D = 384), M = 20, Q = 4 crops of 64..400 px per frame (configs[0], the reference's CPU-runnable plumbing case)
+    C5  one-GPU slice of configs[4]: 100 000-point objects, clouds sharded by instance range (--memory 6250 = one GPU's share of 50 000)
     C4  embed + match + assign only against M = 50 000 instances (configs[3]; one GPU holds the whole embedding memory, or its
         1/N instance range with --shard-memory under torch.distributed)
 A "step" is one pass of the hot path (ObjectMemory.localise body, object_memory.py:911-1131) over one batch of --frames synthetic
@@ -47,6 +48,12 @@ CONFIGS = {
     "C2": dict(model="dinov2_vitb14", memory=1000, points=5000, register=True),
     "C3": dict(model="dator", memory=5000, points=5000, register=True),
     "C4": dict(model="dinov2_vitb14", memory=50000, points=0, register=False),
+    # BASELINE configs[4] ("full localise: 50 k-instance memory + 100 k-point objects, 8 GPUs"): a one-GPU SLICE of it -- the clouds,
+    # resident features and evaluation grid of this rank's instance range (clouds sharded, routed registration; at one rank every
+    # instance is local), 100 000-point objects, 8 frames per step.  --memory sets the slice: 6 250 = one GPU's share of 50 000 instances
+    # (625 M points: 105 GB of compact resident features + 10 GB of clouds); the default keeps the run to a few minutes.
+    "C5": dict(model="dinov2_vitb14", memory=1024, points=100000, register=True, frames=8, shard_clouds=True, compact=True, arena_gb=48.0,
+               steps=3, warmup=1),
 }
 
 
@@ -338,17 +345,17 @@ def rot_err(R_est, R_gt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; C5: 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; C5: 1)")
     ap.add_argument("--config", default="T", choices=sorted(CONFIGS))
-    ap.add_argument("--frames", type=int, default=32, help="query frames per step and per GPU")
+    ap.add_argument("--frames", type=int, default=None, help="query frames per step and per GPU (default 32; C5: 8)")
     ap.add_argument("--memory", type=int, default=None)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--q", type=int, default=None, help="detections per frame (default 7; C1: 4)")
     ap.add_argument("--model", default=None)
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--arena-gb", type=float, default=24.0)
+    ap.add_argument("--arena-gb", type=float, default=None, help="scratch arena of the registration context (default 24; C5: 48)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=0, help="(experiment) N concurrent whole-batch lanes instead of the two-stage pipeline")
     ap.add_argument("--sequential", action="store_true", help="run the steps back to back instead of pipelined")
@@ -357,7 +364,8 @@ def main():
     ap.add_argument("--shard-clouds", action="store_true", help="also shard the memory clouds by instance range: registration jobs run at "
                     "the owner of their targets or fetch the instances they miss, whole-memory evaluation is reduced over the ranks")
     ap.add_argument("--comm", default=None, choices=["torch", "rccl"], help="transport of the sharded layout's collectives: "
-                    "torch.distributed's nccl (= RCCL) group, or the library's own RCCL communicator (ibl_comm_*; default)")
+                    "torch.distributed's nccl (= RCCL) group (default at N > 1), or the library's own RCCL communicator (ibl_comm_*; default "
+                    "at one rank)")
     ap.add_argument("--layout", default="auto", choices=["auto", "sharded", "replicated"],
                     help="N > 1: `sharded` (default) = embedding memory sharded by instance range + RCCL exchange of the per-shard top-k "
                     "candidate lists (north star); `replicated` = every rank holds the whole memory, no data-path collective")
@@ -381,6 +389,13 @@ def main():
     args.register = preset["register"] and args.points > 0
     if args.q is None:
         args.q = preset.get("q", 7)
+    for k, dflt in (("steps", 20), ("warmup", 3), ("frames", 32), ("arena_gb", 24.0)):
+        if getattr(args, k) is None:
+            setattr(args, k, preset.get(k, dflt))
+    if preset.get("shard_clouds"):
+        args.shard_clouds = True
+    if preset.get("compact"):
+        args.compact_features = True
     args.var_crops = bool(preset.get("var_crops", False))
     if args.adjacent_spacing is None:
         args.adjacent_spacing = 0.7 if args.config == "T" else 0.0
@@ -394,8 +409,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.layout == "sharded" or (args.layout == "auto" and world_size > 1 and not args.shard_clouds):
         args.shard_memory = True
-    if args.comm is None:      # (the one-GPU rehearsal with every rank on device 0 cannot use RCCL: it refuses two ranks per device)
-        args.comm = "rccl" if args.shard_memory and os.environ.get("IBL_BENCH_SHARE_GPU", "") != "1" else "torch"
+    if args.comm is None:
+        # N > 1: the collectives of the sharded layout go through torch.distributed's nccl group (= RCCL over xGMI) unless --comm rccl asks
+        # for the library's own communicator (ibl_comm_*): the latter has run with one rank only (tests/test_gpu_multirank.py is its
+        # two-GPU test), and a first multi-GPU run should not depend on it.  One rank: the library's communicator (measured).
+        # (the one-GPU rehearsal with every rank on device 0 cannot use RCCL at all: it refuses two ranks per device)
+        args.comm = "rccl" if args.shard_memory and world_size == 1 and os.environ.get("IBL_BENCH_SHARE_GPU", "") != "1" else "torch"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     # rehearsal of the multi-rank flow on a one-GPU box (not a measurement): IBL_BENCH_SHARE_GPU=1 puts every rank on device 0 and

@@ -127,6 +127,15 @@ typedef struct {
     int64_t tmp_offset;            /* byte offset of this crop's [in_h][out_w][3] scratch in `tmp`   */
 } ibl_crop_desc;
 
+/* One pass of Pillow's 8-bit resampler as a fixed-point table (host function; libImaging/Resample.c precompute_coeffs +
+ * normalize_coeffs_8bpc restated): output samples [win0, win0 + win_n) of a resize in_size -> out_size.  rec: [HOST] win_n records of
+ * (2 + ksize) int32 = [first tap, tap count, 22-bit weights ...]; ksize = ibl_resample_ksize(...).  Returns ksize (> 0) or a negative
+ * status.  What the reference's HF / open_clip processors compute per crop on the CPU (utils/embeddings.py:41-42, 64-65, 86-89). */
+#define IBL_FILTER_BILINEAR 0
+#define IBL_FILTER_BICUBIC 1
+int ibl_resample_ksize(int in_size, int out_size, int filter);
+int ibl_resample_table(int in_size, int out_size, int filter, int win0, int win_n, int32_t* rec);
+
 /* u8 crops -> (optional R<->B swap, utils/embeddings.py:41,64,86) -> PIL-exact resize ->
  * window (centre crop) -> ((u8/255) - mean) / std -> fp16 im2col patch matrix
  * [n_crops * (out_h/patch)*(out_w/patch)][patch_k_pad], k = c*patch*patch + kh*patch + kw.

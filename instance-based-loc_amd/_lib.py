@@ -81,6 +81,8 @@ _SIGS = {
     "ibl_assign_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int]),
     "ibl_assign_candidates": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                         C.c_int, C.c_int]),
+    "ibl_resample_ksize": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ibl_resample_table": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ibl_comm_unique_id": (C.c_int, [vp, C.c_int]),
     "ibl_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
     "ibl_comm_destroy": (C.c_int, [vp]),

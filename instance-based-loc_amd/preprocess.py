@@ -129,6 +129,24 @@ class CropDesc(C.Structure):
 _TABLES = {}            # (in_size, out_size, filter, window) -> (records, ksize): crop sizes recur from batch to batch
 
 
+def resample_tables_native(keys):
+    """`resample_table` through the library's host function `ibl_resample_table` (csrc/resample.cpp: the same float64 arithmetic in C++,
+    microseconds per table); the numpy builders below stay as the checker the CPU tests compare it with."""
+    import ctypes
+    from . import _lib
+    out = {}
+    for key in keys:
+        in_size, out_size, filt, win0, win_n = key
+        f = 1 if filt == BICUBIC else 0
+        ksize = _lib.lib.ibl_resample_ksize(in_size, out_size, f)
+        rec = np.empty((win_n, 2 + ksize), dtype=np.int32)
+        st = _lib.lib.ibl_resample_table(in_size, out_size, f, win0, win_n, rec.ctypes.data_as(ctypes.c_void_p))
+        if st != ksize:
+            _lib.check(st if st < 0 else -1, "ibl_resample_table")
+        out[key] = (rec, ksize)
+    return out
+
+
 def resample_tables(keys):
     """`resample_table` for many (in_size, out_size, filt, win0, win_n) keys in one vectorised pass per (filter, window length): the
     tables of a batch of differently sized crops (two per crop) cost one numpy expression instead of one per table.  Same float64
@@ -219,7 +237,7 @@ def plan_batch(recipe: PreprocessRecipe, shapes):
             if key[0] != key[1] and key not in _TABLES:
                 want.add(key)
     if want:
-        built = resample_tables(sorted(want))
+        built = resample_tables_native(sorted(want))
         if len(_TABLES) + len(built) > 8192:
             _TABLES.clear()
         _TABLES.update(built)

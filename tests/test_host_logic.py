@@ -44,6 +44,30 @@ def test_resample_tables_are_bit_exact_vs_pil():
             assert np.array_equal(_emulate(img, r), ref), (name, h, w)
 
 
+def test_native_and_batched_table_builders_equal_the_pil_checked_one():
+    """the three builders of the same table -- the scalar numpy form the PIL test above pins, the batch-vectorised numpy form and the
+    library's host function `ibl_resample_table` (csrc/resample.cpp, what plan_batch uses) -- agree entry for entry over every recipe and
+    2 000 crop sizes, extreme aspect ratios included"""
+    rng = np.random.default_rng(1)
+    keys = set()
+    for _ in range(500):
+        h, w = int(rng.integers(8, 900)), int(rng.integers(8, 900))
+        for name in ("dinov2", "clip", "vit", "dator_rgb"):
+            r = pp.RECIPES[name]
+            try:
+                rh, rw, top, left = pp.resized_size(r, h, w)
+            except ValueError:
+                continue
+            keys |= {k for k in ((w, rw, r.filt, left, r.out_w), (h, rh, r.filt, top, r.out_h)) if k[0] != k[1]}
+    keys = sorted(keys)
+    native, batched = pp.resample_tables_native(keys), pp.resample_tables(keys)
+    for k in keys:
+        assert native[k][1] == batched[k][1] and np.array_equal(native[k][0], batched[k][0]), k
+    for k in keys[::40]:
+        rec, ksize = pp.resample_table(*k)
+        assert ksize == native[k][1] and np.array_equal(rec, native[k][0]), k
+
+
 def test_plan_batch_shares_tables():
     descs, tables, src_bytes, tmp_bytes, max_h = pp.plan_batch(pp.RECIPES["dinov2"], [(224, 224)] * 5 + [(100, 300)])
     assert descs[0].h_table == descs[4].h_table and descs[5].h_table != descs[0].h_table
