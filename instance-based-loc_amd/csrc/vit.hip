@@ -162,6 +162,9 @@ extern "C" int ibl_gemm_stamps_clear() {
                                     // kt + D into L2.  Measured per ViT-B layer: 1 034 us off, 1 073 / 1 089 / 1 088 us at D = 2 / 3 / 4 --
                                     // the operand stream is not slow because it misses L2
 #endif
+#ifndef IBL_GEMM_RMW_PIPE
+#define IBL_GEMM_RMW_PIPE 1         // residual epilogue: the loads of a row group ahead of the previous group's stores (0: round 3's serial rounds)
+#endif
 #ifndef IBL_GEMM_TOUCH
 #define IBL_GEMM_TOUCH 0            // lab (-DIBL_GEMM_TOUCH=1): L2 touches of the next tile's first stages, one tile early.  Measured: the wait
                                     // at the tile top 6.2 -> 4.9 k clocks, but the K step that carries the touches waits for them (K loop
@@ -586,6 +589,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         asm volatile("" ::"v"(bb[0][0]), "v"(bb[0][1]), "v"(bb[0][2]), "v"(bb[0][3]), "v"(bb[0][4]), "v"(bb[0][5]), "v"(bb[0][6]), "v"(bb[0][7]),
                      "v"(bb[1][0]), "v"(bb[1][1]), "v"(bb[1][2]), "v"(bb[1][3]), "v"(bb[1][4]), "v"(bb[1][5]), "v"(bb[1][6]), "v"(bb[1][7]));
     }
+    float4 b4[4], s4[4];
+    if constexpr (NAT && !PRE) {               // read-modify-write epilogue: bias and scale of this lane's 16 columns, likewise ahead of the pieces
+        const int nbq = ecol0 + wn * 64 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b4[j] = epi.bias ? *reinterpret_cast<const float4*>(epi.bias + nbq + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s4[j] = epi.scale ? *reinterpret_cast<const float4*>(epi.scale + nbq + 16 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#ifndef IBL_GEMM_EPI_BATCHED
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm volatile("" ::"v"(b4[j].x), "v"(b4[j].y), "v"(b4[j].z), "v"(b4[j].w), "v"(s4[j].x), "v"(s4[j].y), "v"(s4[j].z), "v"(s4[j].w));
+#endif
+    }
     tile += gridDim.x;
     const bool has_next = PIPE && tile < nwg;
     if constexpr (PIPE) {
@@ -692,26 +709,79 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         }
 #undef RESID_STORE
 #else
-        float4 b4[4], s4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            b4[j] = epi.bias ? *reinterpret_cast<const float4*>(epi.bias + nb + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-            s4[j] = epi.scale ? *reinterpret_cast<const float4*>(epi.scale + nb + 16 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
+        // (b4 / s4 were fetched before the next tile's pieces went out, above)
+#define RESID_RMW(X, I, PTR)                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
+            float4 x = X[j];                                                                                                        \
+            x.x += (acc[I][j][0] + b4[j].x) * s4[j].x; x.y += (acc[I][j][1] + b4[j].y) * s4[j].y;                                   \
+            x.z += (acc[I][j][2] + b4[j].z) * s4[j].z; x.w += (acc[I][j][3] + b4[j].w) * s4[j].w;                                   \
+            *reinterpret_cast<float4*>((PTR) + 16 * j) = x;                                                                         \
         }
+        if (IBL_GEMM_RMW_PIPE && erow0 + BM <= M) {
+            // Full tile: the read-modify-write of a 16-row group used to be 4 loads, wait, 4 stores -- and since vmcnt retires in order
+            // and counts stores, the wait of group i + 1 also waited for the stores of group i: eight rounds of (store latency + load
+            // latency), 38 k clocks of a proj tile's 85 k.  Now the loads of group i + 1 are issued BEFORE the stores of group i (two
+            // groups of the residual tile in registers instead of one; same arithmetic, same bits), and a round waits for ONE load:
+            //     L0 L1 | wait(4) S0 L2 | wait(8) S1 L3 | ... | wait(8) S6 | wait(4) S7
+            // The memory operations and their waits are inline assembly: with loads AND stores pending the compiler treats vmcnt as
+            // unordered and waits vmcnt(0) at every use (LLVM SIInsertWaitcnts: mixed pending events), which is the serial form again.
+            // No compiler-issued memory operation may sit between them (the kernel has no spills; bias / scale were consumed above).
+            float* const obase = reinterpret_cast<float*>(epi.out) + (int64_t)(erow0 + wm * (MI * 16) + fr) * epi.ldo + nb;
+            const int64_t gstride = 16 * epi.ldo;
+            f32x4 xa[4], xb[4];
+#define RMW_LOAD(X, PTR)                                                                                                            \
+            do {                                                                                                                    \
+                const float* _p = (PTR);                                                                                            \
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(X[0]) : "v"(_p) : "memory");                                 \
+                asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=&v"(X[1]) : "v"(_p) : "memory");                       \
+                asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=&v"(X[2]) : "v"(_p) : "memory");                      \
+                asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=&v"(X[3]) : "v"(_p) : "memory");                      \
+            } while (0)
+#define RMW_WAIT(N, X) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3])::"memory")
+#define RMW_STORE(X, I, PTR)                                                                                                        \
+            do {                                                                                                                    \
+                float* _p = (PTR);                                                                                                  \
+                f32x4 _v[4];                                                                                                        \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                     \
+                    _v[j][0] = X[j][0] + (acc[I][j][0] + b4[j].x) * s4[j].x; _v[j][1] = X[j][1] + (acc[I][j][1] + b4[j].y) * s4[j].y; \
+                    _v[j][2] = X[j][2] + (acc[I][j][2] + b4[j].z) * s4[j].z; _v[j][3] = X[j][3] + (acc[I][j][3] + b4[j].w) * s4[j].w; \
+                }                                                                                                                   \
+                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(_p), "v"(_v[0]) : "memory");                                  \
+                asm volatile("global_store_dwordx4 %0, %1, off offset:64" ::"v"(_p), "v"(_v[1]) : "memory");                        \
+                asm volatile("global_store_dwordx4 %0, %1, off offset:128" ::"v"(_p), "v"(_v[2]) : "memory");                       \
+                asm volatile("global_store_dwordx4 %0, %1, off offset:192" ::"v"(_p), "v"(_v[3]) : "memory");                       \
+            } while (0)
+            static_assert(MI % 2 == 0, "read-modify-write epilogue: row groups in pairs");
+            RMW_LOAD(xa, obase);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
-            if (row >= M) continue;
-            float* orow = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + nb;
+            for (int i = 0; i < MI; i += 2) {
+                RMW_LOAD(xb, obase + (i + 1) * gstride);
+                if (i == 0) RMW_WAIT(4, xa); else RMW_WAIT(8, xa);
+                RMW_STORE(xa, i, obase + i * gstride);
+                if (i + 2 < MI) {
+                    RMW_LOAD(xa, obase + (i + 2) * gstride);
+                    RMW_WAIT(8, xb);
+                } else {
+                    RMW_WAIT(4, xb);
+                }
+                RMW_STORE(xb, i + 1, obase + (i + 1) * gstride);
+            }
+#undef RMW_LOAD
+#undef RMW_WAIT
+#undef RMW_STORE
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float4* o = reinterpret_cast<float4*>(orow + 16 * j);
-                float4 x = *o;
-                x.x += (acc[i][j][0] + b4[j].x) * s4[j].x; x.y += (acc[i][j][1] + b4[j].y) * s4[j].y;
-                x.z += (acc[i][j][2] + b4[j].z) * s4[j].z; x.w += (acc[i][j][3] + b4[j].w) * s4[j].w;
-                *o = x;
+            for (int i = 0; i < MI; ++i) {
+                const int row = erow0 + wm * (MI * 16) + i * 16 + fr;
+                if (row >= M) continue;
+                float* orow = reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + nb;
+                float4 xr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const float4*>(orow + 16 * j);
+                RESID_RMW(xr, i, orow)
             }
         }
+#undef RESID_RMW
 #endif
     } else if (PAIR) {
         const int nb = ecol0 + wn * 64 + 8 * fg;

@@ -48,7 +48,10 @@ SPLIT_SCALE = 64.0          # IBL_VIT_SPLIT_SCALE (include/ibloc.h)
 # random-init weights (DESIGN (c), tools/sim_vit_rounding.py): the residual stream is small in the first blocks, so the patch
 # embedding (18 % of the error variance at 1.3 % of the FLOPs), block 0 (46 %) and block 1 (14 %) carry most of the fp16 rounding
 # error of the embedding; the default gives them exact weights where that is cheap.  "plain" = one term everywhere (rounds 1-2).
-DEFAULT_PRECISION = "p2;0:3232;1:2222"
+# Round 4 (3 584 crops, forward of 224 crops): round 3's "p2;0:3222;1:2211" 7.60e-4 mean / 8.97e-4 max, 15.38 ms; this default (block 0's second
+# LayerNorm output and block 2's QKV weights in two terms as well -- both ride in K-extended launches, no extra launch) 7.26e-4 / 8.59e-4,
+# 15.76 ms; "p2;0:3232;1:2222" 7.14e-4 / 8.49e-4 but 16.14 ms (the second-term launch of an fc2 costs a whole read-modify-write pass).
+DEFAULT_PRECISION = "p2;0:3232;1:2211;2:2111"
 
 
 def parse_precision(spec):

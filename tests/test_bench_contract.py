@@ -44,3 +44,17 @@ def test_bench_gpus_2_starts_two_ranks_and_fails_loudly_without_a_gpu():
     # torchrun terminates the second rank as soon as the first one exits, so only ONE message is guaranteed
     assert out.stderr.count("needs an MI355X") >= 1, out.stderr[-2000:]
     assert not out.stdout.strip().startswith("{")           # no JSON line from a failed run
+
+
+def test_every_config_preset_parses_and_fails_loudly_without_a_gpu():
+    """`bench.py --config X` resolves its preset (model, memory, points, frames / steps defaults, flags) and then stops with the no-GPU message:
+    no preset may die in argument handling before it reaches the device"""
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("checks the GPU-less failure path")
+    for cfg in ("C1", "C2", "C3", "C4", "C5", "T"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg], capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and "needs an MI355X" in out.stderr, (cfg, out.stderr[-500:])

@@ -47,16 +47,21 @@ for name, n_out, n_in, epi in shapes:
         _lib.lib.ibl_gemm_stamps_read(ctypes.c_void_p(buf.ctypes.data), ctypes.c_int(buf.size))
         st = buf.reshape(512, 16, 4).astype(np.float64)
         used = st[:, :, 3] > 0                                            # (block, tile iteration) pairs that ran
-        t0 = st[:, 0, 0][st[:, 0, 0] > 0].min()
+        started = st[:, 0, 0] > 0
+        t0 = st[:, 0, 0][started].min()
         tiles_per_block = used.sum(1)
         blocks = int((tiles_per_block > 0).sum())
         top = (st[:, :, 1] - st[:, :, 0])[used]                           # tile top: wait for the first stage (+ previous stores), barrier
         kl = (st[:, :, 2] - st[:, :, 1])[used]
         ep = (st[:, :, 3] - st[:, :, 2])[used]
         end = st[:, :, 3][used].max() - t0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.lib.ibl_gemm_stamps_clear()
+        e0.record(); V.linear_f16(x, W, b, epi, out=out); e1.record(); torch.cuda.synchronize()
+        one_us = e0.elapsed_time(e1) * 1e3
         first = used.copy(); first[:, 1:] = False
         later = used & ~first
-        print(f"      {blocks} blocks x {tiles_per_block[tiles_per_block > 0].mean():.2f} tiles; s_memtime ticks (100 MHz): kernel {end:.0f}; per tile: "
+        print(f"      {blocks} blocks x {tiles_per_block[tiles_per_block > 0].mean():.2f} tiles; s_memtime ticks: kernel span {end:.0f} ticks = {one_us:.0f} us alone ({end / one_us / 1e3:.2f} ticks / ns); per tile: "
               f"top wait {top.mean():.0f} (first tile {(st[:, :, 1] - st[:, :, 0])[first].mean():.0f}, later {(st[:, :, 1] - st[:, :, 0])[later].mean() if later.any() else 0:.0f}), "
               f"K loop {kl.mean():.0f} (min {kl.min():.0f} max {kl.max():.0f}), prologue(next) + epilogue issue {ep.mean():.0f}; "
               f"block busy sum {(top.sum() + kl.sum() + ep.sum()) / blocks:.0f}")
