@@ -277,8 +277,14 @@ extern "C" int ibl_instance_features_batch(ibl_reg_ctx* ctx, const float* pts4, 
     }
     void* tok;
     ibl_prof_begin(IBL_PROF_ST_FEATURES, 444.0 * (double)(n_seg > 0 ? seg_off_host[n_seg] : 0), s, &tok);
-    // chunks of whole clouds bound the scratch (800 B / point of neighbour lists): a 10k-instance memory is 50M points
-    const int64_t chunk_pts = 1 << 20;
+    // chunks of whole clouds bound the scratch (800 B / point of neighbour lists): a 10k-instance memory is 50M points.  Round 4: at most
+    // 1.5 M points per chunk, and chunks of EQUAL size -- a bench step's 224 detections are 1.105 M points, which the former fixed 2^20-point
+    // chunks split into 1.046 M + 0.059 M: a second round of grid builds, sorts and an almost empty tile search (features are per cloud: the
+    // chunking does not touch the results)
+    const int64_t total_pts = n_seg > 0 ? (int64_t)seg_off_host[n_seg] : 0;
+    const int64_t cap_pts = (int64_t)3 << 19;
+    const int64_t n_chunks = std::max<int64_t>(1, (total_pts + cap_pts - 1) / cap_pts);
+    const int64_t chunk_pts = std::min<int64_t>(cap_pts, (total_pts + n_chunks - 1) / n_chunks + 65536);
     std::vector<int> rebased;
     for (int s0 = 0; s0 < n_seg;) {
         int s1 = s0 + 1;
