@@ -220,7 +220,8 @@ def build_workload(args, rank, world_size, device, reuse=None, n_steps=None):
         comm = comm_reused
     elif args.shard_memory and args.comm == "rccl":          # the library's own RCCL communicator instead of torch.distributed's group
         from ibloc_amd.parallel import RcclComm
-        comm = RcclComm() if world_size > 1 else RcclComm.single()
+        with stdout_to_stderr():
+            comm = RcclComm() if world_size > 1 else RcclComm.single()
     shard = (rank, world_size) if (args.shard_memory and (world_size > 1 or comm is not None)) or args.shard_clouds else None
     # --shard-clouds: this rank keeps the clouds / cached features / evaluation grid of its instance range only; registration jobs are
     # routed between the ranks (ibloc_amd/routing.py).  At one rank it runs the routed path with every instance local.
@@ -311,6 +312,23 @@ def cpu_baseline(args, world, mem_emb, batch, n_frames=1):
         row += q
     dt = time.time() - t0
     return n_frames / dt, dt, threads
+
+
+class stdout_to_stderr:
+    """File-descriptor-level redirect of stdout to stderr for its block: librccl prints a version banner on STDOUT when a communicator is
+    created, and the contract of this script is ONE JSON line on rank 0's stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
 
 
 def spawn_ranks(n):
@@ -425,7 +443,12 @@ def main():
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo" if share_gpu else "nccl")
+        with stdout_to_stderr():             # (the first collective creates the RCCL communicator: its banner goes to stderr)
+            dist.init_process_group("gloo" if share_gpu else "nccl")
+            t0_ = torch.zeros(1, device="cpu" if share_gpu else f"cuda:{local_rank}")
+            dist.all_reduce(t0_)
+            if not share_gpu:
+                torch.cuda.synchronize()
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
