@@ -17,9 +17,12 @@ def _ref(x, W, bias, epi, out0, scale):
     return y
 
 
-# rows cover: ragged last tile of both tile shapes (128 / 256), the M >= 4096 switch to the 256 x 256 tile, a single row
+# rows cover: ragged last tile of both tile shapes (128 / 256), the M >= 4096 switch to the 256 x 256 tile, a single row, a persistent
+# grid that walks three tiles per workgroup
 @pytest.mark.parametrize("rows,n_out,n_in", [(1, 128, 64), (257, 384, 192), (4096, 256, 128), (5000, 768, 768), (4100, 2304, 768),
-                                               (4097, 768, 3072), (300, 3072, 768)])
+                                               (4097, 768, 3072), (300, 3072, 768),
+                                               (66000, 768, 768)])       # 774 tiles on 256 persistent workgroups: several tiles per block, the
+                                                                         # pipelined read-modify-write / store epilogues back to back
 @pytest.mark.parametrize("epi", [0, 1, 2, 4])
 def test_linear_vs_torch(rows, n_out, n_in, epi):
     from ibloc_amd import vit as V
