@@ -34,7 +34,8 @@ def test_head_fp32_vs_oracle(enc):
 
 
 def test_full_forward_vs_oracle_and_reference_golden(enc):
-    """pixels -> embedding through the fp16 streams: rel-L2 <= 2.5e-3 (measured 1.25e-3), cosine >= 0.99999"""
+    """pixels -> embedding through the fp16 streams: rel-L2 <= 2.5e-3 (measured 1.26e-3 -- over SURVEY 8d's 1e-3 gate: DESIGN (c) "DATOR and the
+    1e-3 gate" has the analysis; every block's weights in two terms give 1.03e-3 at +43 % time), cosine >= 0.99999"""
     e, _ = enc
     rng = np.random.default_rng(304)
     rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
