@@ -694,6 +694,63 @@ __device__ inline void pair_features_d(const float4& p1, const float4& n1f, cons
 
 __device__ __forceinline__ int clamp_bin11(int h) { return h < 0 ? 0 : (h >= 11 ? 10 : h); }
 
+// The three SPFH bins of a pair in fp32, or "undecided" (round 4).  pair_features_d spends ~150 fp64 operations (two square roots, five
+// divisions) on a pair whose only output is three bin INDICES: the fp64 values matter where they sit next to a bin boundary, nowhere
+// else.  This evaluates the same expressions in fp32 and calls a pair decided only when every decision on the way -- which normal carries
+// the frame (|a1| < |a2|), the half plane and the five boundary tests of theta, the bins of v . nb and of a -- clears a guard band at least
+// ten times the fp32 error of the value tested (u = 2^-24; inputs are fp32, normals unit to 1 ulp):
+//   d = p2 - p1: one rounding (relative u).  a = (n . d) rsq(|d|^2): absolute error <= 8e-7 -> band 1e-5 on |a1| - |a2| and on 1 - |a|,
+//     5e-5 on the bin fraction of a.
+//   v = d x na: component error <= 6 u |d|; pairs with |v|^2 < 1e-2 |d|^2 (d within 5.7 degrees of the frame's normal) are undecided, for
+//     the rest the normalised v is within 1.3e-5 of the fp64 one, and so are v . nb, w = na x v, y = w . nb and the boundary forms
+//     CK y - SK x -> band SPFH_G = 2e-4 on y and the five forms, 11 / 2 SPFH_G on the bin fraction of v . nb.
+// Undecided pairs (measured: see DESIGN.md) are evaluated by pair_features_d afterwards, so the histograms are those of the fp64 evaluation bit for bit
+// (IBL_SPFH_F64=1 runs every pair in fp64: tests/test_gpu_features.py compares the two).
+#define SPFH_G 2.0e-4f
+__device__ __forceinline__ bool pair_bins_f32(const float4& p1, const float4& n1, const float4& p2, const float4& n2, int* b0, int* b1, int* b2) {
+    float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+    *b0 = 5; *b1 = 5; *b2 = 5;
+    if (dx == 0.0f && dy == 0.0f && dz == 0.0f) return true;                  // coincident points: the zero features' bins (d is exact there)
+    const float r2 = dx * dx + dy * dy + dz * dz;
+    if (r2 < 1.0e-20f) return false;
+    const float rinv = __builtin_amdgcn_rsqf(r2);
+    const float a1 = (n1.x * dx + n1.y * dy + n1.z * dz) * rinv, a2 = (n2.x * dx + n2.y * dy + n2.z * dz) * rinv;
+    const float f1a = fabsf(a1), f2a = fabsf(a2);
+    const bool same_n = n1.x == n2.x && n1.y == n2.y && n1.z == n2.z;          // (planes: a1 == a2 in fp64 as well -> no swap)
+    bool sure = (same_n || fabsf(f1a - f2a) > 1.0e-5f) && fmaxf(f1a, f2a) < 1.0f - 1.0e-5f;
+    const bool swap = f1a < f2a;
+    float nax, nay, naz, nbx, nby, nbz, f3;
+    if (swap) { nax = n2.x; nay = n2.y; naz = n2.z; nbx = n1.x; nby = n1.y; nbz = n1.z; dx = -dx; dy = -dy; dz = -dz; f3 = -a2; }
+    else { nax = n1.x; nay = n1.y; naz = n1.z; nbx = n2.x; nby = n2.y; nbz = n2.z; f3 = a1; }
+    float vx = dy * naz - dz * nay, vy = dz * nax - dx * naz, vz = dx * nay - dy * nax;
+    const float vn2 = vx * vx + vy * vy + vz * vz;
+    sure = sure && vn2 > 1.0e-2f * r2;                                         // sin^2 of the angle between d and the frame's normal
+    const float vinv = __builtin_amdgcn_rsqf(fmaxf(vn2, 1e-30f));
+    vx *= vinv; vy *= vinv; vz *= vinv;
+    const float f2 = vx * nbx + vy * nby + vz * nbz;
+    const float wx = nay * vz - naz * vy, wy = naz * vx - nax * vz, wz = nax * vy - nay * vx;
+    const float x = nax * nbx + nay * nby + naz * nbz, y = wx * nbx + wy * nby + wz * nbz;
+    const float px = -x, py = -y;
+    sure = sure && fabsf(py) > SPFH_G;
+    constexpr float CK[10] = {0.84125353283118121f, 0.41541501300188644f, -0.142314838273285f, -0.65486073394528499f, -0.95949297361449737f,
+                              -0.95949297361449748f, -0.65486073394528521f, -0.14231483827328523f, 0.41541501300188605f, 0.84125353283118121f};
+    constexpr float SK[10] = {0.54064081745559756f, 0.90963199535451833f, 0.9898214418809328f, 0.75574957435425827f, 0.28173255684142967f,
+                              -0.28173255684142939f, -0.75574957435425816f, -0.98982144188093268f, -0.90963199535451855f, -0.54064081745559744f};
+    int bin = py >= 0.0f ? 0 : 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float t = py >= 0.0f ? CK[k] * py - SK[k] * px : CK[k + 5] * py - SK[k + 5] * px;
+        sure = sure && fabsf(t) > SPFH_G;
+        bin += t >= 0.0f ? 1 : 0;
+    }
+    const float g1 = 11.0f * (f2 + 1.0f) * 0.5f, g2 = 11.0f * (f3 + 1.0f) * 0.5f;
+    const float fl1 = floorf(g1), fl2 = floorf(g2);
+    constexpr float GB1 = 5.5f * SPFH_G, GB2 = 5.0e-5f;
+    sure = sure && (g1 - fl1) > GB1 && (g1 - fl1) < 1.0f - GB1 && (g2 - fl2) > GB2 && (g2 - fl2) < 1.0f - GB2;
+    *b0 = bin; *b1 = clamp_bin11((int)fl1); *b2 = clamp_bin11((int)fl2);
+    return sure;
+}
+
 template <class Acc>
 struct SpfhConsumer {
     static constexpr bool WANTS_INNER = false;
@@ -1914,31 +1971,94 @@ __global__ __launch_bounds__(256) void ibl_normals_from_mask_kernel(const float4
     normal_from_moments(c, k, qi, normals);
 }
 
-// SPFH histograms from stored neighbour lists (after the fused search above has written lists and normals): wave per point
+// SPFH histograms from stored neighbour lists (after the fused search above has written lists and normals): wave per point.
+// FAST: the bins of a pair come from pair_bins_f32; the pairs it cannot decide are collected per point and appended, with ONE atomic per
+// point that has any, to one of SPFH_NQ queues (consecutive workgroups use different queues: a single counter serialises ~10^6 returning
+// atomics per batch at the L2 -- measured, it doubled the stage), then evaluated in fp64 by ibl_spfh_queue_kernel, which adds their three
+// counts to the stored byte histograms.
+#define SPFH_NQ 256
+#define SPFH_QSTRIDE 64                 // ints between two queue counters (256 B: different L2 channels)
+template <bool FAST>
 __global__ __launch_bounds__(256) void ibl_spfh_lists_kernel(const float4* __restrict__ pts, const float4* __restrict__ normals,
                                                              const int* __restrict__ nbr_idx, const int* __restrict__ nbr_cnt, int K, int n,
-                                                             unsigned char* __restrict__ spfh_cnt) {
+                                                             unsigned char* __restrict__ spfh_cnt, int2* __restrict__ queue, int* __restrict__ q_count,
+                                                             int q_cap) {
     __shared__ int hists[4][36];
+    __shared__ int stash[4][FAST ? 128 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qi = blockIdx.x * 4 + wave;
-    if (qi >= n) return;
+    // the fp64 form doubles as the fast form's overflow path: launched behind it with the queues' overflow flag (the word after the last
+    // counter), it returns at once unless a queue overflowed, and then rewrites every histogram (grid-stride over the points)
+    if (!FAST && q_count != nullptr && q_count[SPFH_NQ * SPFH_QSTRIDE] == 0) return;
     int* hist = hists[wave];
+  for (int qi = blockIdx.x * 4 + wave; qi < n; qi += gridDim.x * 4) {
     if (lane < 36) hist[lane] = 0;
     wave_lds_sync();
     const int k = nbr_cnt[qi];
     const float4 q = pts[qi], qn = normals[qi];
-    for (int t = lane; t < k; t += 64) {
-        const int jo = nbr_idx[(int64_t)qi * K + t];
+    int n_unsure = 0;
+    for (int t0 = 0; t0 < k; t0 += 64) {
+        const int t = t0 + lane;
+        const int jo = t < k ? nbr_idx[(int64_t)qi * K + t] : qi;
+        bool unsure = false;
         if (jo != qi) {
-            double f[3];
-            pair_features_d(q, qn, pts[jo], normals[jo], f);
-            atomicAdd(&hist[clamp_bin11((int)f[0])], 1);
-            atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
-            atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
+            if (FAST) {
+                int b0, b1, b2;
+                if (pair_bins_f32(q, qn, pts[jo], normals[jo], &b0, &b1, &b2)) {
+                    atomicAdd(&hist[b0], 1);
+                    atomicAdd(&hist[11 + b1], 1);
+                    atomicAdd(&hist[22 + b2], 1);
+                } else {
+                    unsure = true;
+                }
+            } else {
+                double f[3];
+                pair_features_d(q, qn, pts[jo], normals[jo], f);
+                atomicAdd(&hist[clamp_bin11((int)f[0])], 1);
+                atomicAdd(&hist[11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5))], 1);
+                atomicAdd(&hist[22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))], 1);
+            }
+        }
+        if (FAST) {
+            const unsigned long long m = __ballot(unsure);
+            if (unsure) stash[wave][(n_unsure + __popcll(m & ((1ull << lane) - 1ull))) & 127] = jo;      // (K <= 128: ibl_normals_fpfh_fusable)
+            n_unsure += __popcll(m);
         }
     }
     wave_lds_sync();
     if (lane < 36) spfh_cnt[(int64_t)qi * 36 + lane] = lane < 33 ? (unsigned char)hist[lane] : (unsigned char)0;
+    if (FAST && n_unsure > 0) {
+        const int qsel = blockIdx.x & (SPFH_NQ - 1);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&q_count[qsel * SPFH_QSTRIDE], n_unsure);
+        base = __shfl(base, 0, 64);
+        if (base + n_unsure <= q_cap) {
+            for (int e = lane; e < n_unsure; e += 64) queue[(int64_t)qsel * q_cap + base + e] = make_int2(qi, stash[wave][e]);
+        } else if (lane == 0) {
+            q_count[SPFH_NQ * SPFH_QSTRIDE] = 1;           // this queue is full: the gated fp64 launch redoes the batch
+        }
+    }
+    wave_lds_sync();
+  }
+}
+
+// the undecided pairs of the fast kernel, in fp64: three byte counters of the point's stored histogram go up by one each (a 32-bit atomic on
+// the word that holds the byte: a counter never exceeds the 100 neighbours of a point, so no carry crosses into the next byte).
+// Grid: SPFH_NQ x 4 workgroups, four per queue.
+__global__ __launch_bounds__(256) void ibl_spfh_queue_kernel(const float4* __restrict__ pts, const float4* __restrict__ normals,
+                                                             const int2* __restrict__ queue, const int* __restrict__ q_count, int q_cap,
+                                                             unsigned char* __restrict__ spfh_cnt) {
+    if (q_count[SPFH_NQ * SPFH_QSTRIDE] != 0) return;            // (overflow: everything is redone)
+    const int qsel = blockIdx.x & (SPFH_NQ - 1), part = blockIdx.x / SPFH_NQ, parts = gridDim.x / SPFH_NQ;
+    const int total = min(q_count[qsel * SPFH_QSTRIDE], q_cap);
+    for (int e = part * 256 + threadIdx.x; e < total; e += parts * 256) {
+        const int2 pr = queue[(int64_t)qsel * q_cap + e];
+        double f[3];
+        pair_features_d(pts[pr.x], normals[pr.x], pts[pr.y], normals[pr.y], f);
+        const int b[3] = {clamp_bin11((int)f[0]), 11 + clamp_bin11((int)floor(11 * (f[1] + 1.0) * 0.5)), 22 + clamp_bin11((int)floor(11 * (f[2] + 1.0) * 0.5))};
+        unsigned* words = reinterpret_cast<unsigned*>(spfh_cnt + (int64_t)pr.x * 36);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&words[b[c] >> 2], 1u << (8 * (b[c] & 3)));
+    }
 }
 
 // normals + FPFH from ONE neighbour search (requires radius_normal <= radius_feature, max_nn_normal <= max_nn_feature and <= NP_MAXK)
@@ -1963,8 +2083,42 @@ int ibl_launch_normals_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* 
     if (st) return st;
     hipLaunchKernelGGL(ibl_normals_from_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, nbr_idx, max_nn_feature, nrm_mask, n, normals);
     IBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ibl_spfh_lists_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pts, normals, nbr_idx, nbr_cnt, max_nn_feature, n, spfh);
-    IBL_LAUNCH_CHECK();
+    {
+        // fp32 bins + fp64 for the pairs next to a bin boundary (pair_bins_f32); the SPFH_NQ queues together hold 1 / 16 of all pairs
+        // (measured: 0.8 % are undecided) -- a batch that overflows one is redone in fp64 by the gated third launch; IBL_SPFH_F64=1 runs
+        // every pair in fp64 (the tests compare both), IBL_SPFH_QCAP=<entries per queue> shrinks the queues (the overflow test)
+        const char* e64 = getenv("IBL_SPFH_F64");
+        bool fast = !(e64 && atoi(e64));
+        if (fast) {
+            int64_t cap64 = std::min<int64_t>((int64_t)n * max_nn_feature / (16 * SPFH_NQ) + 256, (int64_t)1 << 20);
+            if (const char* ec = getenv("IBL_SPFH_QCAP")) cap64 = std::max<int64_t>(1, atoll(ec));
+            int2* queue; int* q_count;
+            IBL_ARENA(queue, int2, cap64 * SPFH_NQ);
+            IBL_ARENA(q_count, int, SPFH_NQ * SPFH_QSTRIDE + 64);
+            IBL_HIP_CHECK(hipMemsetAsync(q_count, 0, sizeof(int) * (SPFH_NQ * SPFH_QSTRIDE + 1), s));
+            hipLaunchKernelGGL(ibl_spfh_lists_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, s, pts, normals, nbr_idx, nbr_cnt, max_nn_feature, n, spfh,
+                               queue, q_count, (int)cap64);
+            IBL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ibl_spfh_queue_kernel, dim3(SPFH_NQ * 4), dim3(256), 0, s, pts, normals, queue, q_count, (int)cap64, spfh);
+            IBL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ibl_spfh_lists_kernel<false>, dim3(2048), dim3(256), 0, s, pts, normals, nbr_idx, nbr_cnt, max_nn_feature, n, spfh,
+                               (int2*)nullptr, q_count, (int)cap64);
+            IBL_LAUNCH_CHECK();
+            if (const char* es = getenv("IBL_SPFH_STATS"); es && atoi(es)) {              // diagnostics: undecided pairs of this batch (synchronises)
+                std::vector<int> cnt(SPFH_NQ * SPFH_QSTRIDE + 1);
+                IBL_HIP_CHECK(hipMemcpyAsync(cnt.data(), q_count, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, s));
+                IBL_HIP_CHECK(hipStreamSynchronize(s));
+                long long tot = 0; int mx = 0;
+                for (int i = 0; i < SPFH_NQ; ++i) { tot += cnt[i * SPFH_QSTRIDE]; mx = std::max(mx, cnt[i * SPFH_QSTRIDE]); }
+                fprintf(stderr, "[ibloc] spfh: %lld undecided pairs of at most %lld; fullest queue %d of %lld; overflow %d\n", tot,
+                        (long long)n * max_nn_feature, mx, (long long)cap64, cnt.back());
+            }
+        } else {
+            hipLaunchKernelGGL(ibl_spfh_lists_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, s, pts, normals, nbr_idx, nbr_cnt, max_nn_feature, n, spfh,
+                               (int2*)nullptr, (int*)nullptr, 0);
+            IBL_LAUNCH_CHECK();
+        }
+    }
     if (fpfh) {
         hipLaunchKernelGGL(ibl_fpfh_kernel, dim3((n + FPFH_Q - 1) / FPFH_Q), dim3(256), 0, s, spfh, nbr_idx, nbr_d2, nbr_cnt, max_nn_feature, n, matching_order, fpfh);
         IBL_LAUNCH_CHECK();

@@ -18,6 +18,7 @@ order-preserving boolean compaction only.
 """
 import os
 import warnings
+from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 
@@ -308,6 +309,7 @@ class LocaliseEngine:
         runs on a second stream, driven by a worker thread, while stage B of batch k (registration) executes; results are those
         of `localise_batch`, yielded in order.  The two stages touch disjoint state: the encoder / match workspaces belong to
         stage A, the registration arena to stage B."""
+        depth = max(1, int(kw.pop("lookahead", os.environ.get("IBL_STAGE_A_LOOKAHEAD", "2"))))
         if self.route is not None:
             # sharded clouds: stage B has collectives of its own (routing.py); two threads issuing collectives on one group could pair
             # them up differently on different ranks, so the batches run one after the other
@@ -342,39 +344,49 @@ class LocaliseEngine:
             if any_active:
                 raise RuntimeError("sharded memory: the ranks were given different numbers of batches")
 
+        # Stage A runs up to `lookahead` batches ahead of stage B (default 2, $IBL_STAGE_A_LOOKAHEAD).  With one batch of lookahead stage A of
+        # batch k + 1 starts together with stage B of batch k and ends first (17 against 21 ms of GPU work on the bench workload), so the
+        # end of every stage B -- the late ICP iterations, launches of a few workgroups each -- ran with most of the chip idle; a second
+        # batch in flight keeps the encoder's GEMMs queued behind them.  The worker thread is the only one that issues stage-A work (and
+        # every collective), in batch order, whatever the depth.
         fut_done = None
         it = iter(batches)
-        cur = next(it, None)
+        pending = deque()
+        exhausted = False
         if self._pool_a is None:
             self._pool_a = ThreadPoolExecutor(max_workers=1)
-        if cur is None:
-            if self.exchange is not None:
-                self._pool_a.submit(stage_done).result()
-            return
-        fut = submit(cur)
+
+        def fill():
+            nonlocal exhausted, fut_done
+            while not exhausted and len(pending) < depth:
+                b = next(it, None)
+                if b is None:
+                    exhausted = True
+                    if self.exchange is not None:
+                        fut_done = self._pool_a.submit(stage_done)
+                else:
+                    pending.append((b, submit(b)))
+
         try:
-            while cur is not None:
+            fill()
+            while pending:
+                cur, fut = pending[0]
                 assns = fut.result()
-                fut = None
-                nxt = next(it, None)
-                if nxt is not None:
-                    fut = submit(nxt)
-                elif self.exchange is not None:
-                    fut_done = self._pool_a.submit(stage_done)
+                pending.popleft()
+                fill()
                 args = dict(kw)
                 for k in ("seed", "job_id_base"):
                     if k in cur:
                         args[k] = cur[k]
                 yield self.localise_batch(cur["det"], cur["q_per_frame"], assns=assns, **args)
-                cur = nxt
             if fut_done is not None:
                 fut_done.result()
         finally:
             # an abandoned generator or a raising batch must not leave stage A running on the side stream with the lane-0 encoder
             # workspace: a later localise_batch on the caller's stream would race with it
-            if fut is not None:
+            for _, f in pending:
                 try:
-                    fut.result()
+                    f.result()
                 except Exception:
                     pass
             side.synchronize()

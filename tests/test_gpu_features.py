@@ -101,6 +101,35 @@ def test_fused_normals_and_feature_search_equals_the_two_searches(ctx, monkeypat
     assert torch.equal(n1, n2) and torch.equal(f1, f2)
 
 
+def test_spfh_fp32_bins_with_fp64_for_undecided_pairs_equal_the_fp64_bins(ctx, monkeypatch):
+    """round 4: the SPFH bins of a pair come from fp32 arithmetic when every decision clears a guard band (pair_bins_f32, csrc/reg_knn.hip)
+    and from the fp64 pair features otherwise (queue + second kernel).  IBL_SPFH_F64=1 evaluates every pair in fp64; IBL_SPFH_QCAP=8
+    overflows the queue, which the gated fp64 launch repairs: all three must give the same bytes -- noisy surfaces, exact planes (equal
+    normals, theta on a bin boundary for every pair), a cloud 200 m from the origin, tiny and empty clouds"""
+    from ibloc_amd.registration import CloudBatch, instance_features_batch
+    rng = np.random.default_rng(79)
+    cs = clouds([6000, 3000, 1200, 40, 3, 0], 13)
+    g = np.stack(np.meshgrid(np.arange(60), np.arange(60), indexing="ij"), -1).reshape(-1, 2) * 0.011
+    cs.append(np.concatenate([g, np.zeros((len(g), 1))], 1).astype(np.float32))                           # an exact plane on a lattice
+    cs.append((np.concatenate([g, 0.002 * rng.normal(size=(len(g), 1))], 1) + [211.5, -187.25, 3.0]).astype(np.float32))
+    cs.append((rng.uniform(-0.05, 0.05, size=(3000, 3))).astype(np.float32))
+    box = rng.uniform(-0.2, 0.2, size=(6000, 3))
+    box[np.arange(6000), rng.integers(0, 3, 6000)] = rng.choice([-0.2, 0.2], 6000)                        # the six faces of a cube
+    cs.append(box.astype(np.float32))
+    b = CloudBatch.from_numpy(cs)
+    got = instance_features_batch(ctx, b, 0.05)
+    monkeypatch.setenv("IBL_SPFH_F64", "1")
+    ref = instance_features_batch(ctx, b, 0.05)
+    monkeypatch.delenv("IBL_SPFH_F64")
+    monkeypatch.setenv("IBL_SPFH_QCAP", "8")
+    over = instance_features_batch(ctx, b, 0.05)
+    torch.cuda.synchronize()
+    assert ctx.status() == 0
+    assert float(ref.fpfh[:b.n].abs().sum()) > 0
+    assert torch.equal(got.fpfh[:b.n], ref.fpfh[:b.n]) and torch.equal(got.normals[:b.n], ref.normals[:b.n])
+    assert torch.equal(over.fpfh[:b.n], ref.fpfh[:b.n])
+
+
 def test_guess_threshold_selection_equals_the_two_pass_selection(ctx, monkeypatch):
     """round 3: the tile search collects the candidates below a GUESS of the k-th neighbour's distance in one pass and selects from that
     list (tile_select_guess); IBL_KNN_NOGUESS=1 runs the two-pass histogram selection for every query: neighbour sets, normals, FPFH
