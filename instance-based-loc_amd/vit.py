@@ -19,6 +19,7 @@ FLAG_FINAL_LN = 4
 FLAG_QUICK_GELU = 8
 FLAG_PROJ = 16
 FLAG_OUT_ALL_TOKENS = 32
+FLAG_ACT_TERMS = 64          # IBL_VIT_ACT_TERMS: some block takes the input of a residual GEMM in two terms (o / fc2 = 3)
 MAX_LAYERS = 32
 
 
@@ -33,7 +34,7 @@ class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ls1", "ln2_g", "ln2_b",
                                           "w_fc1", "b_fc1", "w_fc2", "b_fc2", "ls2",
                                           "w_qkv_x", "w_o_lo", "ls1_lo", "w_fc1_x", "w_fc2_lo", "ls2_lo")] + \
-               [("qkv_terms", C.c_int32), ("fc1_terms", C.c_int32)]
+               [("qkv_terms", C.c_int32), ("fc1_terms", C.c_int32), ("o_terms", C.c_int32), ("fc2_terms", C.c_int32)]
 
 
 class VitWeights(C.Structure):
@@ -44,7 +45,8 @@ class VitWeights(C.Structure):
 SPLIT_SCALE = 64.0          # IBL_VIT_SPLIT_SCALE (include/ibloc.h)
 
 # Which operands of which blocks get a second fp16 term ("p<terms>;<layer>:<qkv><o><fc1><fc2>;...", layer "*" = every other block; qkv / fc1: 1, 2 (weights) or 3
-# (weights + LayerNorm output), o / fc2 / p(atch embedding): 1 or 2 (weights)).  Measured on the 12-layer ViT-B/14 with the seeded
+# (weights + LayerNorm output), o / fc2: 1, 2 (weights) or 3 (weights + the attention output / the GELU hidden layer in two terms: one more
+# accumulating launch each, round 4), p(atch embedding): 1 or 2 (weights)).  Measured on the 12-layer ViT-B/14 with the seeded
 # random-init weights (DESIGN (c), tools/sim_vit_rounding.py): the residual stream is small in the first blocks, so the patch
 # embedding (18 % of the error variance at 1.3 % of the FLOPs), block 0 (46 %) and block 1 (14 %) carry most of the fp16 rounding
 # error of the embedding; the default gives them exact weights where that is cheap.  "plain" = one term everywhere (rounds 1-2).
@@ -70,7 +72,7 @@ def parse_precision(spec):
         else:
             l, t = part.split(":")
             t = tuple(int(c) for c in t)
-            if len(t) != 4 or not all(1 <= v <= 3 for v in t) or t[1] > 2 or t[3] > 2:
+            if len(t) != 4 or not all(1 <= v <= 3 for v in t):
                 raise ValueError(f"bad precision entry {part!r}")
             layers["*" if l.strip() == "*" else int(l)] = t      # "*": every block without an entry of its own
     if patch not in (1, 2):
@@ -315,6 +317,8 @@ class VitEncoder:
                 if tq > 1:
                     L.w_qkv_x = dev_f16(split_terms(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0), tq))
                     L.qkv_terms = tq
+                L.o_terms, L.fc2_terms = to, t2
+                self._act_terms = getattr(self, "_act_terms", False) or to > 2 or t2 > 2
                 if to > 1:
                     L.w_o_lo = dev_f16(weight_lo(w_o))
                     if not fold:                             # (no vector: the library adds the term with the factor 1 / S, residual preloaded)
@@ -333,6 +337,7 @@ class VitEncoder:
         flags |= FLAG_FINAL_LN if cfg.final_ln else 0
         flags |= FLAG_PROJ if cfg.proj_dim else 0
         flags |= FLAG_OUT_ALL_TOKENS if cfg.out_all_tokens else 0
+        flags |= FLAG_ACT_TERMS if getattr(self, "_act_terms", False) else 0
         nrun = cfg.depth if cfg.n_blocks_run < 0 else cfg.n_blocks_run
         self.desc = VitDesc(cfg.dim, cfg.depth, cfg.heads, cfg.mlp_dim, cfg.patch, cfg.img_h, cfg.img_w, cfg.n_tokens,
                             cfg.patch_k_pad, flags, nrun, cfg.out_dim, cfg.ln_eps)

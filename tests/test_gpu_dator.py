@@ -34,9 +34,12 @@ def test_head_fp32_vs_oracle(enc):
 
 
 def test_full_forward_vs_oracle_and_reference_golden(enc):
-    """pixels -> embedding through the fp16 streams: rel-L2 <= 2.5e-3 (measured 1.26e-3 -- over SURVEY 8d's 1e-3 gate: DESIGN (c) "DATOR and the
-    1e-3 gate" has the analysis; every block's weights in two terms give 1.03e-3 at +43 % time), cosine >= 0.99999"""
-    e, _ = enc
+    """pixels -> embedding through the streams under DATOR's default plan (three-term operands in every block, dator.DEFAULT_PRECISION):
+    SURVEY 8d's gate, rel-L2 < 1e-3, on the golden of the reference's own build_FourDNet (white-noise pixels, the harshest input: measured
+    9.3e-4 for the batch); the ViT encoders' plan (dator.FAST_PRECISION, 2.1x faster) stays within 2x of its measured 1.26e-3"""
+    from ibloc_amd import dator as D
+    e, (rw, dw, hw) = enc
+    assert e.precision == D.DEFAULT_PRECISION == "p2;*:3333"
     rng = np.random.default_rng(304)
     rgb = rng.normal(size=(3, 3, 256, 128)).astype(np.float32)
     depth = np.repeat(rng.uniform(-1, 1, size=(3, 1, 256, 128)).astype(np.float32), 3, axis=1)
@@ -45,7 +48,41 @@ def test_full_forward_vs_oracle_and_reference_golden(enc):
     rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     cos = np.min(np.sum(got * ref, -1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(ref, axis=-1)))
     print("dator rel_l2", rel, "cos", cos)
-    assert rel <= 2.5e-3 and cos >= 0.99999
+    assert rel < 1e-3 and cos >= 0.999999
+    fast = D.DatorEncoder(rw, dw, hw, precision=D.FAST_PRECISION)
+    got_f = fast.forward_pixels(torch.from_numpy(rgb), torch.from_numpy(depth)).cpu().numpy()
+    rel_f = np.linalg.norm(got_f - ref) / np.linalg.norm(ref)
+    print("dator rel_l2 under the ViT plan", rel_f)
+    assert rel < rel_f <= 2.5e-3
+
+
+def test_embedding_gate_per_crop_on_u8_crops():
+    """SURVEY 8d's gate crop by crop: 224 u8 crops + depth crops of the bench generator through the product's preprocessing, both streams and
+    the head, against the fp32 oracle (torch on the device for the streams, the oracle's own preprocessing of the depth crops): every
+    embedding within 1e-3 (measured over 448 crops: mean 3.1e-4, max 5.6e-4; the ViT plan: 1.2e-3 / 3.0e-3)"""
+    import bench
+    from ibloc_amd import dator as D
+    from oracle import vit_oracle as vo
+    rw, dw, hw = D.random_stream_weights(20), D.random_stream_weights(21), D.random_head_weights(22)
+    e = D.DatorEncoder(rw, dw, hw)
+    frw = {k: torch.from_numpy(v).cuda() for k, v in D.fold_lora(rw).items()}
+    fdw = {k: torch.from_numpy(v).cuda() for k, v in D.fold_lora(dw).items()}
+    rng = np.random.default_rng(3)
+    rgb, dep = bench.Crops("dator", 21).variants(list(rng.integers(0, 100000, size=224)), rng, "cuda")
+    rels = []
+    for i in range(0, 224, 112):
+        pr, img = e.rgb.preprocess(rgb[i:i + 112], want_u8=True)
+        got = e.head(e.rgb.forward_patches(pr), e.depth.forward_patches(e.preprocess_depth(dep[i:i + 112]))).cpu().numpy()
+        mean = torch.tensor(e.rgb.recipe.mean, dtype=torch.float32, device="cuda")
+        std = torch.tensor(e.rgb.recipe.std, dtype=torch.float32, device="cuda")
+        xr = (((img.to(torch.float64) * (1 / 255)).to(torch.float32) - mean) / std).permute(0, 3, 1, 2).contiguous()
+        xd = torch.from_numpy(np.stack([do.preprocess_depth(d) for d in dep[i:i + 112].cpu().numpy()]))
+        ref = do.head_forward(hw, vo.vit_forward(frw, D.STREAM_CFG, xr, all_tokens=True, device="cuda"),
+                              vo.vit_forward(fdw, D.STREAM_CFG, xd, all_tokens=True, device="cuda"))
+        rels.append(np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1))
+    rels = np.concatenate(rels)
+    print(f"[gate dator] plan {e.precision}: embedding rel-L2 mean {rels.mean():.2e} max {rels.max():.2e} over {len(rels)} crops")
+    assert rels.max() < 1e-3 and rels.mean() < 6e-4
 
 
 def test_preprocess_and_facade(enc):
@@ -63,7 +100,8 @@ def test_preprocess_and_facade(enc):
     got = e.embed(crops, depths).cpu().numpy()
     exp = do.forward(rw, dw, hw, D.STREAM_CFG, np.stack([do.preprocess_rgb(c) for c in crops]), exp_px)
     rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
-    assert rel <= 3e-3
+    print("dator facade rel_l2", rel)
+    assert rel < 1e-3
     # the reference-shaped entry point: bbox crop of the full depth image
     emb.set_encoder("dator", e)
     full_depth = rng.uniform(0.3, 8.0, size=(200, 240)).astype(np.float32)
@@ -72,7 +110,9 @@ def test_preprocess_and_facade(enc):
                                    device="cuda")
     assert out.shape == (128,)
     exp1 = do.forward(rw, dw, hw, D.STREAM_CFG, do.preprocess_rgb(crops[0])[None], do.preprocess_depth(full_depth[30:150, 20:110])[None])[0]
-    assert np.linalg.norm(out.cpu().numpy() - exp1) / np.linalg.norm(exp1) <= 3e-3
+    rel1 = np.linalg.norm(out.cpu().numpy() - exp1) / np.linalg.norm(exp1)
+    print("dator facade (bbox crop) rel_l2", rel1)
+    assert rel1 < 1e-3
 
 
 def test_load_encoder_from_a_reference_shaped_checkpoint(tmp_path):
@@ -91,5 +131,5 @@ def test_load_encoder_from_a_reference_shaped_checkpoint(tmp_path):
     depth = np.repeat(rng.uniform(-1, 1, size=(3, 1, 256, 128)).astype(np.float32), 3, axis=1)
     got = e.forward_pixels(torch.from_numpy(rgb), torch.from_numpy(depth)).cpu().numpy()
     ref = GOLD["embedding"]
-    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 2.5e-3
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
     assert emb._encoder("dator") is e

@@ -47,7 +47,8 @@ def test_c3_dator_encoder_in_the_engine():
     mem_o = do.embed(fr, fd, wh, list(mem_rgb), list(mem_dep)).reshape(M, E, 128)
     det_o = do.embed(fr, fd, wh, list(q_rgb), list(q_dep))
     rel = np.linalg.norm(mem_emb - mem_o) / np.linalg.norm(mem_o)
-    assert rel < 3e-3, rel
+    print("C3 memory embeddings rel-L2 vs the fp32 oracle:", rel)
+    assert rel < 1e-3, rel
     off = (np.arange(M + 1) * E).astype(np.int32)
     memn = mo.normalize_rows(mem_o.reshape(M * E, 128))
     r0 = 0
