@@ -309,4 +309,17 @@ __device__ inline void kabsch_from_moments(const double* sm, const double* dm, d
     }
     T[12] = T[13] = T[14] = 0.0; T[15] = 1.0;
 }
+// Workgroup id -> position in a launch whose consecutive positions share data (the points of one cloud, the cells of one region).
+// The dispatcher deals workgroups round-robin over the 8 XCDs, each with its own 4 MB L2: taken as is, the ~2 000 workgroups in flight put
+// every cloud of that window into every L2 (8 MB of points against 4 MB: the gathers of ibl_normals_from_mask_kernel missed the L2 on
+// nearly every access, 2.5 KB of memory-side traffic per point).  Here XCD x walks the x-th contiguous eighth of the launch instead.
+__device__ __forceinline__ int ibl_xcd_block(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = bid & 7;
+    return x * q + (x < r ? x : r) + (bid >> 3);
+}
+#ifdef IBL_NO_XCD_REMAP          // lab: the dispatcher's order
+#define IBL_XCD_BLOCK(b, nb) ((int)(b))
+#else
+#define IBL_XCD_BLOCK(b, nb) ibl_xcd_block((int)(b), (int)(nb))
+#endif
 #endif  // __HIPCC__

@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(256) void ibl_fpfh_kernel(const unsigned char* __re
     __shared__ double accs[FPFH_Q][33];
     __shared__ int kq[FPFH_Q];
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * FPFH_Q;
+    const int q0 = IBL_XCD_BLOCK(blockIdx.x, gridDim.x) * FPFH_Q;
     if (tid < FPFH_Q) kq[tid] = q0 + tid < n ? nbr_cnt[q0 + tid] : 0;
     __syncthreads();
     int kmax = 0;
@@ -1932,7 +1932,7 @@ int ibl_launch_fpfh(ibl_reg_ctx* ctx, const BatchGrid& g, const float4* pts, con
 // normal_solve -- a point's normal does not depend on which kernel found its neighbours.
 __global__ __launch_bounds__(256) void ibl_normals_from_mask_kernel(const float4* __restrict__ pts, const int* __restrict__ nbr_idx, int K,
                                                                     const unsigned* __restrict__ nrm_mask, int n, float4* __restrict__ normals) {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int qi = IBL_XCD_BLOCK(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (qi >= n) return;
     const uint4 m4 = *reinterpret_cast<const uint4*>(nrm_mask + 4 * (int64_t)qi);
     const unsigned w[4] = {m4.x, m4.y, m4.z, m4.w};
@@ -1990,7 +1990,7 @@ __global__ __launch_bounds__(256) void ibl_spfh_lists_kernel(const float4* __res
     // counter), it returns at once unless a queue overflowed, and then rewrites every histogram (grid-stride over the points)
     if (!FAST && q_count != nullptr && q_count[SPFH_NQ * SPFH_QSTRIDE] == 0) return;
     int* hist = hists[wave];
-  for (int qi = blockIdx.x * 4 + wave; qi < n; qi += gridDim.x * 4) {
+  for (int qi = IBL_XCD_BLOCK(blockIdx.x, gridDim.x) * 4 + wave; qi < n; qi += gridDim.x * 4) {
     if (lane < 36) hist[lane] = 0;
     wave_lds_sync();
     const int k = nbr_cnt[qi];

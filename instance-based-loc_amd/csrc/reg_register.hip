@@ -2096,26 +2096,54 @@ __global__ __launch_bounds__(256) void ibl_evaluate_kernel(ibl_memgrid g, const 
         const int x0 = (int)floorf((qx - thr) * g.inv), x1 = (int)floorf((qx + thr) * g.inv);
         const int y0 = (int)floorf((qy - thr) * g.inv), y1 = (int)floorf((qy + thr) * g.inv);
         const int z0 = (int)floorf((qz - thr) * g.inv), z1 = (int)floorf((qz + thr) * g.inv);
-        for (int ix = x0; ix <= x1; ++ix)
-            for (int iy = y0; iy <= y1; ++iy)
-                for (int iz = z0; iz <= z1; ++iz) {
-                    const unsigned long long k = mg_key(ix, iy, iz);
-                    unsigned long long h = mg_hash(k) & g.hmask;
-                    int c = -1;
-                    while (true) {
-                        const unsigned long long tk = g.tkeys[h];
-                        if (tk == k) { c = g.tvals[h]; break; }
-                        if (tk == MG_EMPTY) break;
-                        h = (h + 1) & g.hmask;
-                    }
-                    if (c < 0) continue;
-                    const int b = g.ustart[c], e = g.ustart[c + 1];
-                    for (int t = b; t < e; ++t) {
-                        const float4 m = g.sorted[t];
-                        const float d2 = dist2f(qx, qy, qz, m.x, m.y, m.z);
-                        if (d2 < best) { best = d2; found = true; }
-                    }
+        // The query's own cell first, then the (up to seven) others of its +-thr box only while they can still hold a closer point:
+        // a neighbouring cell lies behind the face it shares with the own cell, so the distance to that face (per axis that differs) bounds
+        // every point of it from below.  Round 4: an inlier's nearest point is millimetres away and the faces are centimetres away, so ~1.5
+        // instead of 8 cells are looked up and read (1.6 of the 1.9 GB a launch moved were the points of those cells).  The bound is
+        // conservative -- the slack covers the rounding of floorf(x * inv) against the geometric face, which grows with the coordinate -- and
+        // a cell is skipped only when its bound already reaches the best: the minimum is that of the full scan.
+        const int hx = (int)floorf(qx * g.inv), hy = (int)floorf(qy * g.inv), hz = (int)floorf(qz * g.inv);
+        auto scan_cell = [&](int ix, int iy, int iz) {
+            const unsigned long long k = mg_key(ix, iy, iz);
+            unsigned long long h = mg_hash(k) & g.hmask;
+            int c = -1;
+            while (true) {
+                const unsigned long long tk = g.tkeys[h];
+                if (tk == k) { c = g.tvals[h]; break; }
+                if (tk == MG_EMPTY) break;
+                h = (h + 1) & g.hmask;
+            }
+            if (c < 0) return;
+            const int b = g.ustart[c], e = g.ustart[c + 1];
+            for (int t = b; t < e; t += 4) {           // four points in flight (past the end: the last point again -- a repeat changes no minimum)
+                float4 m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[u] = g.sorted[min(t + u, e - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d2 = dist2f(qx, qy, qz, m[u].x, m[u].y, m[u].z);
+                    if (d2 < best) { best = d2; found = true; }
                 }
+            }
+        };
+        auto face_gap = [&](int i, int hcell, float q) {   // distance from q to the face between its own cell and cell i on this axis (0: same cell)
+            if (i == hcell) return 0.0f;
+            const float face = (float)(i < hcell ? hcell : hcell + 1) * g.cell;
+            return fmaxf(fabsf(q - face) - (1e-3f * g.cell + 5e-7f * fabsf(face)), 0.0f);
+        };
+        scan_cell(hx, hy, hz);
+        for (int ix = x0; ix <= x1; ++ix) {
+            const float gx = face_gap(ix, hx, qx);
+            for (int iy = y0; iy <= y1; ++iy) {
+                const float gy = face_gap(iy, hy, qy);
+                for (int iz = z0; iz <= z1; ++iz) {
+                    if (ix == hx && iy == hy && iz == hz) continue;
+                    const float gz = face_gap(iz, hz, qz);
+                    if (gx * gx + gy * gy + gz * gz >= best) continue;
+                    scan_cell(ix, iy, iz);
+                }
+            }
+        }
         if (found) { cnt += 1.0; err2 += (double)best; }
         if (d2_out) d2_out[job.out + (i - job.begin)] = found ? best : INFINITY;
     }

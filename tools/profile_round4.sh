@@ -20,9 +20,9 @@ a)
 b)
     timeout -k 10 300 python3 bench.py --config C1 > $OUT/bench_C1.json
     timeout -k 10 300 python3 bench.py --config C2 --cpu-frames 0 --ransac-budget 0 > $OUT/bench_C2.json
-    timeout -k 10 400 python3 bench.py --config C3 --ransac-budget 0 > $OUT/bench_C3_dator.json
+    timeout -k 10 600 python3 bench.py --config C3 --ransac-budget 0 > $OUT/bench_C3_dator.json
     timeout -k 10 300 python3 bench.py --config C4 --cpu-frames 0 > $OUT/bench_C4_m50000.json
-    timeout -k 10 300 python3 bench.py --config C4 --cpu-frames 0 --layout sharded > $OUT/bench_C4_m50000_shard_rccl_world1.json
+    timeout -k 10 700 python3 bench.py --config C4 --cpu-frames 0 --layout sharded > $OUT/bench_C4_m50000_shard_rccl_world1.json
     ;;
 c)
     mkdir -p $OUT/pmc
