@@ -56,7 +56,8 @@ int ibl_prof_read(int id, double* ms, double* units, int64_t* launches);
 #define IBL_VIT_QUICK_GELU 8      /* x*sigmoid(1.702x) (OpenAI CLIP); laion2b ViT-B-32 uses GELU   */
 #define IBL_VIT_PROJ 16           /* CLS -> out_dim projection (CLIP visual.proj)                  */
 #define IBL_VIT_OUT_ALL_TOKENS 32 /* return every token (DATOR/TransReID local_feature=True)       */
-#define IBL_VIT_ACT_TERMS 64      /* some block has o_terms / fc2_terms = 3: the workspace carries the second activation terms   */
+#define IBL_VIT_ACT_TERMS2 64     /* some block has o_terms / fc2_terms = 2: attention output / hidden layer as rows of 2 terms  */
+#define IBL_VIT_ACT_TERMS3 128    /* ... = 3: rows of 3 terms (sizes the workspace)                                             */
 #define IBL_VIT_SPLIT_SCALE 64.0f /* S of the two-term operands below                              */
 
 typedef struct {
@@ -95,11 +96,13 @@ typedef struct {                   /* all [dev]; weights fp16 [N][K] row-major (
     const void* w_fc1_x;                         /* fp16 [mlp_dim][fc1_terms*dim] or NULL              */
     const void* w_fc2_lo; const float* ls2_lo;  /* fp16 [dim][mlp_dim]; fp32 [dim]                    */
     int32_t qkv_terms, fc1_terms;                /* 1 (or 0), 2 or 3                                   */
-    /* round 4: 3 = the INPUT of the residual GEMM in two fp16 terms as well (needs w_o_lo / w_fc2_lo and IBL_VIT_ACT_TERMS in the
-     * descriptor's flags): the attention kernel writes a_lo * S next to its output; fc1 runs with an fp32 output and a GELU pass writes
-     * hidden_hi and hidden_lo * S; each is one more accumulating launch scale_lo[n] * (a_lo W_hi^T).  0 / 1 / 2: as before (the second
-     * WEIGHT term is selected by the non-NULL w_o_lo / w_fc2_lo alone). */
+    /* round 4: the two residual GEMMs with K-extended operands as well -- ONE launch of K' = terms * K instead of one read-modify-write pass
+     * over the residual per term: the attention kernel / the fc1 epilogue write the rows [a_hi | a_hi / S] (terms 2) or
+     * [a_hi | a_lo * S | a_hi / S] (terms 3: + the second fp16 term of the attention output / of the GELU hidden layer); w_o_x / w_fc2_x are laid
+     * out like w_qkv_x.  Needs IBL_VIT_ACT_TERMS2 / 3 in the descriptor's flags.  With w_o_x / w_fc2_x NULL the older w_o_lo / w_fc2_lo launches run. */
     int32_t o_terms, fc2_terms;
+    const void* w_o_x;                           /* fp16 [dim][o_terms*dim] or NULL                     */
+    const void* w_fc2_x;                         /* fp16 [dim][fc2_terms*mlp_dim] or NULL               */
 } ibl_vit_layer;
 
 typedef struct {

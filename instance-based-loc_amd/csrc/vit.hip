@@ -54,15 +54,15 @@ enum { EPI_BIAS_H16 = 0, EPI_BIAS_GELU_H16 = 1, EPI_RESID_F32 = 2, EPI_PATCH_F32
        // x += alpha * (a W^T + bias), alpha a power of two, with the residual tile PRELOADED into the accumulators: the MFMA chain starts
        // from (x + bias) / alpha and the epilogue is 32 plain stores per lane -- no read-modify-write after the K loop (round 4)
        EPI_RESID_PRE_F32 = 5,
-       // EPI_BIAS_GELU_H16 with the hidden layer in two fp16 terms: out = hi, out_lo = (value - hi) * S (fc2_terms = 3, round 4)
-       EPI_BIAS_GELU_H16X2 = 6 };
+       // EPI_BIAS_GELU_H16 writing K-extended operand rows for the next GEMM (round 4; ldo = terms * N):
+       //   KX2: [h | h / S]  (fc2 weights in two terms)     KX3: [h | (value - h) * S | h / S]  (+ the hidden layer's second term)
+       EPI_BIAS_GELU_H16KX2 = 6, EPI_BIAS_GELU_H16KX3 = 7 };
 
 struct GemmEpi {
     const float* bias;      // [N] or null
     const float* scale;     // [N] LayerScale or null (EPI_RESID)
     const float* pos;       // [P][N] position embedding rows for patches (EPI_PATCH)
     void* out;              // fp16 or fp32
-    void* out_lo;           // EPI_BIAS_GELU_H16X2: second term of the output (same shape and stride)
     int64_t ldo;            // output row stride (elements)
     int tokens_per_crop;    // T (EPI_PATCH)
     int patches_per_crop;   // P (EPI_PATCH)
@@ -198,9 +198,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
     constexpr bool PRE = EPI == EPI_RESID_PRE_F32;
     // fp16 epilogues: MFMA row 4 fg + r of n-tile j is weight row 32 (j / 2) + 8 fg + 4 (j % 2) + r: a lane owns 8 consecutive
     // columns (one 16-byte store) of n-tile pair j / 2 and the four lane groups cover 64 contiguous bytes of the row
-    constexpr bool X2 = EPI == EPI_BIAS_GELU_H16X2;
-    constexpr bool PAIR = EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16 || X2;
-    constexpr int PAIR_STORES = (X2 ? 4 : 2) * MI;          // stores per lane of a full tile's fp16 epilogue
+    constexpr int GT = EPI == EPI_BIAS_GELU_H16KX3 ? 3 : (EPI == EPI_BIAS_GELU_H16KX2 ? 2 : 1);     // column blocks the fp16 epilogue writes
+    constexpr bool GELU = EPI == EPI_BIAS_GELU_H16 || GT > 1;
+    constexpr bool PAIR = EPI == EPI_BIAS_H16 || GELU;
+    constexpr int PAIR_STORES = GT * 2 * MI;          // stores per lane of a full tile's fp16 epilogue
 #define KEYW(r) (NAT ? keyx_act<BK>(r) : (PAIR ? keyx_pair<BK>(r) : keyx_w<BK>(r)))
     const int nbn = N / BN;
     const int nbm = (M + BM - 1) / BM;
@@ -798,21 +799,23 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
             _Pragma("unroll") for (int t = 0; t < 8; t += 2) {                                                                      \
                 f32x2 x = {acc[I][2 * j2 + (t >> 2)][t & 3], acc[I][2 * j2 + (t >> 2)][(t & 3) + 1]};                               \
                 x += f32x2{bb[j2][t], bb[j2][t + 1]};                                                                               \
-                if (EPI == EPI_BIAS_GELU_H16 || X2) x = gelu_erf2(x);                                                               \
+                if (GELU) x = gelu_erf2(x);                                                                                         \
                 v[t] = x.x; v[t + 1] = x.y;                                                                                         \
             }                                                                                                                       \
             const uint4 hi4 = make_uint4(f2h_pk(v[0], v[1]), f2h_pk(v[2], v[3]), f2h_pk(v[4], v[5]), f2h_pk(v[6], v[7]));           \
             *reinterpret_cast<uint4*>((OROW) + 32 * j2) = hi4;                                                                      \
-            if (X2) {                                                                                                               \
+            if (GT > 1) {                                                                                                           \
                 const unsigned hw_[4] = {hi4.x, hi4.y, hi4.z, hi4.w};                                                               \
-                unsigned lw_[4];                                                                                                    \
-                _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                       \
-                    lw_[t] = f2h_pk((v[2 * t] - h2f((u16)(hw_[t] & 0xFFFFu))) * IBL_VIT_SPLIT_SCALE,                                \
-                                    (v[2 * t + 1] - h2f((u16)(hw_[t] >> 16))) * IBL_VIT_SPLIT_SCALE);                               \
-                *reinterpret_cast<uint4*>((OROW) + lo_off + 32 * j2) = make_uint4(lw_[0], lw_[1], lw_[2], lw_[3]);                  \
+                unsigned lw_[4], sw_[4];                                                                                            \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                     \
+                    const float h0 = h2f((u16)(hw_[t] & 0xFFFFu)), h1 = h2f((u16)(hw_[t] >> 16));                                   \
+                    sw_[t] = f2h_pk(h0 * (1.0f / IBL_VIT_SPLIT_SCALE), h1 * (1.0f / IBL_VIT_SPLIT_SCALE));                          \
+                    lw_[t] = f2h_pk((v[2 * t] - h0) * IBL_VIT_SPLIT_SCALE, (v[2 * t + 1] - h1) * IBL_VIT_SPLIT_SCALE);              \
+                }                                                                                                                   \
+                if (GT == 3) *reinterpret_cast<uint4*>((OROW) + N + 32 * j2) = make_uint4(lw_[0], lw_[1], lw_[2], lw_[3]);          \
+                *reinterpret_cast<uint4*>((OROW) + (GT - 1) * (int64_t)N + 32 * j2) = make_uint4(sw_[0], sw_[1], sw_[2], sw_[3]);   \
             }                                                                                                                       \
         }
-        const int64_t lo_off = X2 ? reinterpret_cast<u16*>(epi.out_lo) - reinterpret_cast<u16*>(epi.out) : 0;
         if (erow0 + BM <= M) {                 // full tile (all but the last row of tiles): no per-row branch between the stores
             u16* const obase = reinterpret_cast<u16*>(epi.out) + (int64_t)(erow0 + wm * (MI * 16) + fr) * epi.ldo + nb;
             const int64_t gstride = 16 * epi.ldo;
@@ -850,8 +853,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
-        if (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16 || EPI == EPI_BIAS_GELU_H16X2) {
-            if (EPI == EPI_BIAS_GELU_H16 || EPI == EPI_BIAS_GELU_H16X2) {
+        if (PAIR) {
+            if (GELU) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) v[t] = gelu_erf(v[t]);
             }
@@ -861,14 +864,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void ibl_gemm_f16_tn(const u16* 
             uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<u16*>(epi.out) + (int64_t)row * epi.ldo + n0);
             o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-            if (EPI == EPI_BIAS_GELU_H16X2) {
+            if (GT > 1) {
+                unsigned int lk[8], sk[8];
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    pk[t] = (unsigned int)f2h((v[2 * t] - h2f((u16)(pk[t] & 0xFFFFu))) * IBL_VIT_SPLIT_SCALE) |
-                            ((unsigned int)f2h((v[2 * t + 1] - h2f((u16)(pk[t] >> 16))) * IBL_VIT_SPLIT_SCALE) << 16);
-                uint4* ol = reinterpret_cast<uint4*>(reinterpret_cast<u16*>(epi.out_lo) + (int64_t)row * epi.ldo + n0);
-                ol[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                ol[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                for (int t = 0; t < 8; ++t) {
+                    const float h0 = h2f((u16)(pk[t] & 0xFFFFu)), h1 = h2f((u16)(pk[t] >> 16));
+                    sk[t] = (unsigned int)f2h(h0 * (1.0f / IBL_VIT_SPLIT_SCALE)) | ((unsigned int)f2h(h1 * (1.0f / IBL_VIT_SPLIT_SCALE)) << 16);
+                    lk[t] = (unsigned int)f2h((v[2 * t] - h0) * IBL_VIT_SPLIT_SCALE) | ((unsigned int)f2h((v[2 * t + 1] - h1) * IBL_VIT_SPLIT_SCALE) << 16);
+                }
+                if (GT == 3) {
+                    o[N / 8] = make_uint4(lk[0], lk[1], lk[2], lk[3]);
+                    o[N / 8 + 1] = make_uint4(lk[4], lk[5], lk[6], lk[7]);
+                }
+                o[(GT - 1) * (N / 8)] = make_uint4(sk[0], sk[1], sk[2], sk[3]);
+                o[(GT - 1) * (N / 8) + 1] = make_uint4(sk[4], sk[5], sk[6], sk[7]);
             }
         } else if (EPI == EPI_RESID_F32) {
             float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(epi.out) + (int64_t)row * epi.ldo + n0);
@@ -1134,9 +1143,11 @@ __global__ void ibl_set_cls_kernel(float* __restrict__ x, const float* __restric
 #ifndef ATT_THREADS
 #define ATT_THREADS 512
 #endif
-template <int NT, bool LO = false>
+// TERMS: the output as K-extended operand rows for the projection (row stride TERMS * D; round 4): 2 = [a | a / S] (projection weights
+// in two terms), 3 = [a | (value - a) * S | a / S] (+ the attention output's own second term)
+template <int NT, int TERMS = 1>
 __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int T,
-                                                            int D, int heads, float scale, int cls_only, u16* __restrict__ out_lo) {
+                                                            int D, int heads, float scale, int cls_only) {
     constexpr int KEYS = NT * 16;
     constexpr int KROW = 144;               // bytes per K row (64 fp16 + 16 B pad)
     constexpr int VROW = KEYS * 2 + 16;     // bytes per V^T row
@@ -1262,28 +1273,29 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void ibl_attention_kernel(const u16
         const int qg = qt * 16 + fr;
         if (qg < (cls_only ? 1 : T)) {
             const float inv = 1.0f / sum;
-            u16* orow = out + (tok0 + qg) * (int64_t)D + h * 64 + 4 * fg;
+            u16* orow = out + (tok0 + qg) * (int64_t)(TERMS * D) + h * 64 + 4 * fg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                uint2 pk;
-                pk.x = (unsigned)f2h(o[dt][0] * inv) | ((unsigned)f2h(o[dt][1] * inv) << 16);
-                pk.y = (unsigned)f2h(o[dt][2] * inv) | ((unsigned)f2h(o[dt][3] * inv) << 16);
-                *reinterpret_cast<uint2*>(orow + dt * 16) = pk;
-            }
-            if (LO) {                // second fp16 term of the output, times S (o_terms = 3: the projection's input in two terms)
-                u16* lrow = out_lo + (tok0 + qg) * (int64_t)D + h * 64 + 4 * fg;
+                float v[4];
+                unsigned short h4[4];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    unsigned short l4[4];
+                for (int r = 0; r < 4; ++r) { v[r] = o[dt][r] * inv; h4[r] = f2h(v[r]); }
+                uint2 pk;
+                pk.x = (unsigned)h4[0] | ((unsigned)h4[1] << 16);
+                pk.y = (unsigned)h4[2] | ((unsigned)h4[3] << 16);
+                *reinterpret_cast<uint2*>(orow + dt * 16) = pk;
+                if (TERMS > 1) {
+                    unsigned short l4[4], s4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = o[dt][r] * inv;
-                        l4[r] = f2h((v - h2f(f2h(v))) * IBL_VIT_SPLIT_SCALE);
+                        const float hf = h2f(h4[r]);
+                        s4[r] = f2h(hf * (1.0f / IBL_VIT_SPLIT_SCALE));
+                        l4[r] = f2h((v[r] - hf) * IBL_VIT_SPLIT_SCALE);
                     }
-                    uint2 pk;
-                    pk.x = (unsigned)l4[0] | ((unsigned)l4[1] << 16);
-                    pk.y = (unsigned)l4[2] | ((unsigned)l4[3] << 16);
-                    *reinterpret_cast<uint2*>(lrow + dt * 16) = pk;
+                    if (TERMS == 3)
+                        *reinterpret_cast<uint2*>(orow + D + dt * 16) = make_uint2((unsigned)l4[0] | ((unsigned)l4[1] << 16), (unsigned)l4[2] | ((unsigned)l4[3] << 16));
+                    *reinterpret_cast<uint2*>(orow + (TERMS - 1) * D + dt * 16) =
+                        make_uint2((unsigned)s4[0] | ((unsigned)s4[1] << 16), (unsigned)s4[2] | ((unsigned)s4[3] << 16));
                 }
             }
         }
@@ -1328,27 +1340,28 @@ extern "C" int64_t ibl_vit_workspace_bytes(const ibl_vit_desc* d, int batch) {
     bytes += R * d->dim * 4;          // x
     bytes += R * d->dim * 2 * 3;      // xn (up to three terms per row, two-term operands of the early blocks)
     bytes += R * 3 * d->dim * 2;      // qkv
-    bytes += R * d->dim * 2;          // attn out
-    bytes += R * d->mlp_dim * 2;      // mlp hidden
+    const int at = (d->flags & IBL_VIT_ACT_TERMS3) ? 3 : ((d->flags & IBL_VIT_ACT_TERMS2) ? 2 : 1);   // widest K-extended input of a residual GEMM
+    bytes += R * d->dim * 2 * at;     // attn out
+    bytes += R * d->mlp_dim * 2 * at; // mlp hidden
     bytes += rows_pad(batch) * d->dim * 2 + rows_pad(batch) * d->dim * 4;  // final rows (fp16 + f32)
-    if (d->flags & IBL_VIT_ACT_TERMS) bytes += R * d->dim * 2 + R * d->mlp_dim * 2;   // second terms of the attention output and of the hidden layer
     return bytes + 9 * 256;
 }
 
-static int run_attention(const u16* qkv, u16* out, int B, int T, int D, int heads, int cls_only, hipStream_t s, u16* out_lo = nullptr) {
+static int run_attention(const u16* qkv, u16* out, int B, int T, int D, int heads, int cls_only, hipStream_t s, int terms = 1) {
     const float scale = 0.125f;   // 1/sqrt(64)
     const int nt = (T + 15) / 16;
     dim3 grid(B * heads), block(ATT_THREADS);
 #define IBL_ATT(NTV)                                                                                      \
     do {                                                                                                  \
-        if (out_lo) hipLaunchKernelGGL((ibl_attention_kernel<NTV, true>), grid, block, 0, s, qkv, out, T, D, heads, scale, cls_only, out_lo);   \
-        else hipLaunchKernelGGL((ibl_attention_kernel<NTV, false>), grid, block, 0, s, qkv, out, T, D, heads, scale, cls_only, out_lo);          \
+        if (terms == 3) hipLaunchKernelGGL((ibl_attention_kernel<NTV, 3>), grid, block, 0, s, qkv, out, T, D, heads, scale, cls_only);        \
+        else if (terms == 2) hipLaunchKernelGGL((ibl_attention_kernel<NTV, 2>), grid, block, 0, s, qkv, out, T, D, heads, scale, cls_only);   \
+        else hipLaunchKernelGGL((ibl_attention_kernel<NTV, 1>), grid, block, 0, s, qkv, out, T, D, heads, scale, cls_only);                    \
     } while (0)
     if (getenv("IBL_DEBUG_OCC")) {
         int nb = -1;
         hipFuncAttributes fa{};
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ibl_attention_kernel<17, false>, ATT_THREADS, 0);
-        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ibl_attention_kernel<17, false>));
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ibl_attention_kernel<17, 1>, ATT_THREADS, 0);
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ibl_attention_kernel<17, 1>));
         fprintf(stderr, "[occ] attention<17>: %d blocks/CU, %d regs, %zu B static LDS\n", nb, fa.numRegs, fa.sharedSizeBytes);
     }
     if (nt <= 4) IBL_ATT(4);
@@ -1386,13 +1399,10 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
     float* x = reinterpret_cast<float*>(carve(p, R * D * 4));
     u16* xn = reinterpret_cast<u16*>(carve(p, R * D * 2 * 3));
     u16* qkv = reinterpret_cast<u16*>(carve(p, R * 3 * D * 2));
-    u16* att = reinterpret_cast<u16*>(carve(p, R * D * 2));
-    u16* hid = reinterpret_cast<u16*>(carve(p, R * d->mlp_dim * 2));
+    const int at = (d->flags & IBL_VIT_ACT_TERMS3) ? 3 : ((d->flags & IBL_VIT_ACT_TERMS2) ? 2 : 1);
+    u16* att = reinterpret_cast<u16*>(carve(p, R * D * 2 * at));
+    u16* hid = reinterpret_cast<u16*>(carve(p, R * d->mlp_dim * 2 * at));
     u16* fin_bf = reinterpret_cast<u16*>(carve(p, rows_pad(batch) * D * 2));
-    (void)carve(p, rows_pad(batch) * D * 4);
-    const bool act_terms = (d->flags & IBL_VIT_ACT_TERMS) != 0;
-    u16* att_lo = act_terms ? reinterpret_cast<u16*>(carve(p, R * D * 2)) : nullptr;
-    u16* hid_lo = act_terms ? reinterpret_cast<u16*>(carve(p, R * d->mlp_dim * 2)) : nullptr;
 
     int st;
     // patch embedding (conv as GEMM over im2col'ed patches) + position embedding, scattered into x
@@ -1459,29 +1469,28 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
             st = launch_gemm<EPI_BIAS_H16>(xn, TD, reinterpret_cast<const u16*>(L->w_qkv), D, batch, D, D, q, s);
             if (st) return st;
         }
-        const bool o3 = !cls_only && L->o_terms >= 3, f3 = !cls_only && L->fc2_terms >= 3;
-        if ((o3 && !L->w_o_lo) || (f3 && !L->w_fc2_lo) || ((o3 || f3) && !act_terms))
-            return ibl_set_error(IBL_ERR_ARG, "ibl_vit_forward: layer %d: o_terms / fc2_terms = 3 need the second weight term and IBL_VIT_ACT_TERMS", l);
-        st = run_attention(qkv, att, batch, T, D, H, cls_only ? 1 : 0, s, o3 ? att_lo : nullptr);
+        // K-extended inputs of the two residual GEMMs (w_o_x / w_fc2_x; round 4): ONE launch of K' = terms * K instead of one
+        // read-modify-write pass over the residual per term
+        const int ot = (!cls_only && L->w_o_x && L->o_terms > 1) ? L->o_terms : 1;
+        const int f2t = (!cls_only && L->w_fc2_x && L->fc2_terms > 1) ? L->fc2_terms : 1;
+        if (ot > at || f2t > at || ot > 3 || f2t > 3)
+            return ibl_set_error(IBL_ERR_ARG, "ibl_vit_forward: layer %d: o_terms / fc2_terms %d / %d need IBL_VIT_ACT_TERMS%d in the descriptor", l, ot, f2t, ot > f2t ? ot : f2t);
+        st = run_attention(qkv, att, batch, T, D, H, cls_only ? 1 : 0, s, ot);
         if (st) return st;
         {
             GemmEpi e{};
-            e.bias = L->b_o; e.scale = L->ls1; e.out = x; e.ldo = cls_only ? TD : D; e.alpha = 1.0f;
+            e.bias = L->b_o; e.scale = L->ls1; e.out = x; e.ldo = cls_only ? TD : D; e.alpha = 1.0f; e.algo_k = D;
+            const u16* wo = reinterpret_cast<const u16*>(ot > 1 ? L->w_o_x : L->w_o);
+            const int64_t lda = cls_only ? TD : (int64_t)ot * D;
             // no LayerScale vector (none in the model, or folded into W_o / b_o by the host): the residual tile is preloaded into the
-            // accumulators (EPI_RESID_PRE_F32); with one, the read-modify-write epilogue applies it
-            st = (L->ls1 || !gemm_resid_pre()) ? launch_gemm<EPI_RESID_F32>(att, cls_only ? TD : D, reinterpret_cast<const u16*>(L->w_o), D, cls_only ? batch : (int)Rn, D, D, e, s)
-                        : launch_gemm<EPI_RESID_PRE_F32>(att, cls_only ? TD : D, reinterpret_cast<const u16*>(L->w_o), D, cls_only ? batch : (int)Rn, D, D, e, s);
+            // accumulators (EPI_RESID_PRE_F32, lab); with one, the read-modify-write epilogue applies it
+            st = (L->ls1 || !gemm_resid_pre()) ? launch_gemm<EPI_RESID_F32>(att, lda, wo, (int64_t)ot * D, cls_only ? batch : (int)Rn, D, ot * D, e, s)
+                        : launch_gemm<EPI_RESID_PRE_F32>(att, lda, wo, (int64_t)ot * D, cls_only ? batch : (int)Rn, D, ot * D, e, s);
             if (st) return st;
-            if (!cls_only && L->w_o_lo) {                    // second weight term: x += (ls1 / S) * (att W_lo'^T); without a vector x += (att W_lo'^T) / S
-                                                             // (the preloading kernel: it carries the power-of-two factor)
+            if (!cls_only && ot == 1 && L->w_o_lo) {         // (older form) second weight term as its own launch: x += (ls1 / S) * (att W_lo'^T)
                 e.bias = nullptr; e.scale = L->ls1_lo; e.algo_k = -1; e.alpha = 1.0f / IBL_VIT_SPLIT_SCALE;
                 st = L->ls1_lo ? launch_gemm<EPI_RESID_F32>(att, D, reinterpret_cast<const u16*>(L->w_o_lo), D, (int)Rn, D, D, e, s)
                                : launch_gemm<EPI_RESID_PRE_F32>(att, D, reinterpret_cast<const u16*>(L->w_o_lo), D, (int)Rn, D, D, e, s);
-                if (st) return st;
-            }
-            if (o3) {                                        // second term of the attention output: x += (ls1 / S) * (att_lo W_hi^T)
-                st = L->ls1_lo ? launch_gemm<EPI_RESID_F32>(att_lo, D, reinterpret_cast<const u16*>(L->w_o), D, (int)Rn, D, D, e, s)
-                               : launch_gemm<EPI_RESID_PRE_F32>(att_lo, D, reinterpret_cast<const u16*>(L->w_o), D, (int)Rn, D, D, e, s);
                 if (st) return st;
             }
         }
@@ -1496,35 +1505,27 @@ extern "C" int ibl_vit_forward(const ibl_vit_desc* d, const ibl_vit_weights* w, 
         const int mlp_rows = cls_only ? batch : (int)Rn;
         {
             GemmEpi e{};
-            e.bias = L->b_fc1; e.out = hid; e.ldo = d->mlp_dim; e.algo_k = D;
+            e.bias = L->b_fc1; e.out = hid; e.ldo = (int64_t)f2t * d->mlp_dim; e.algo_k = D;
             if (d->flags & IBL_VIT_QUICK_GELU)
                 return ibl_set_error(IBL_ERR_UNSUPPORTED, "ibl_vit_forward: QuickGELU not built");
-            if (f3) {            // hidden layer in two terms: the GELU epilogue writes hi and lo * S
-                e.out_lo = hid_lo;
-                st = launch_gemm<EPI_BIAS_GELU_H16X2>(mlp_in, (int64_t)ft * D, reinterpret_cast<const u16*>(ft > 1 ? L->w_fc1_x : L->w_fc1), (int64_t)ft * D,
-                                                      mlp_rows, d->mlp_dim, ft * D, e, s);
-                if (st) return st;
-            } else {
-            st = launch_gemm<EPI_BIAS_GELU_H16>(mlp_in, (int64_t)ft * D, reinterpret_cast<const u16*>(ft > 1 ? L->w_fc1_x : L->w_fc1), (int64_t)ft * D,
-                                                mlp_rows, d->mlp_dim, ft * D, e, s);
+            const u16* w1 = reinterpret_cast<const u16*>(ft > 1 ? L->w_fc1_x : L->w_fc1);
+            if (f2t == 3) st = launch_gemm<EPI_BIAS_GELU_H16KX3>(mlp_in, (int64_t)ft * D, w1, (int64_t)ft * D, mlp_rows, d->mlp_dim, ft * D, e, s);
+            else if (f2t == 2) st = launch_gemm<EPI_BIAS_GELU_H16KX2>(mlp_in, (int64_t)ft * D, w1, (int64_t)ft * D, mlp_rows, d->mlp_dim, ft * D, e, s);
+            else st = launch_gemm<EPI_BIAS_GELU_H16>(mlp_in, (int64_t)ft * D, w1, (int64_t)ft * D, mlp_rows, d->mlp_dim, ft * D, e, s);
             if (st) return st;
-            }
         }
         {
             GemmEpi e{};
-            e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = cls_only ? TD : D; e.alpha = 1.0f;
-            st = (L->ls2 || !gemm_resid_pre()) ? launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s)
-                        : launch_gemm<EPI_RESID_PRE_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
+            e.bias = L->b_fc2; e.scale = L->ls2; e.out = x; e.ldo = cls_only ? TD : D; e.alpha = 1.0f; e.algo_k = d->mlp_dim;
+            const u16* w2 = reinterpret_cast<const u16*>(f2t > 1 ? L->w_fc2_x : L->w_fc2);
+            const int64_t k2 = (int64_t)f2t * d->mlp_dim;
+            st = (L->ls2 || !gemm_resid_pre()) ? launch_gemm<EPI_RESID_F32>(hid, k2, w2, k2, mlp_rows, D, (int)k2, e, s)
+                        : launch_gemm<EPI_RESID_PRE_F32>(hid, k2, w2, k2, mlp_rows, D, (int)k2, e, s);
             if (st) return st;
-            if (!cls_only && L->w_fc2_lo) {
+            if (!cls_only && f2t == 1 && L->w_fc2_lo) {
                 e.bias = nullptr; e.scale = L->ls2_lo; e.algo_k = -1; e.alpha = 1.0f / IBL_VIT_SPLIT_SCALE;
                 st = L->ls2_lo ? launch_gemm<EPI_RESID_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2_lo), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s)
                                : launch_gemm<EPI_RESID_PRE_F32>(hid, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2_lo), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
-                if (st) return st;
-            }
-            if (f3) {
-                st = L->ls2_lo ? launch_gemm<EPI_RESID_F32>(hid_lo, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s)
-                               : launch_gemm<EPI_RESID_PRE_F32>(hid_lo, d->mlp_dim, reinterpret_cast<const u16*>(L->w_fc2), d->mlp_dim, mlp_rows, D, d->mlp_dim, e, s);
                 if (st) return st;
             }
         }

@@ -20,13 +20,13 @@ STREAM_CFG = V.VitConfig("transreid_b16", 768, 12, 12, 3072, 16, 256, 128, (16, 
                          n_blocks_run=11, out_all_tokens=True, recipe="dator_rgb")
 
 # Operand-term plan of the two TransReID streams (ibloc_amd.vit syntax).  Round 4: every GEMM of every block with three-term operands --
-# weights hi + lo, and the GEMM's input hi + lo: the LayerNorm outputs (K-extended rows), the attention output (second output of the
-# attention kernel) and the GELU hidden layer (second output of the fc1 epilogue).  SURVEY 8d's gate is 1e-3 per embedding; with the ViT
+# weights hi + lo, and the GEMM's input hi + lo: the LayerNorm outputs, the attention output and the GELU hidden layer, all as K-extended
+# rows [a_hi | a_lo S | a_hi / S] written by the producing kernel (one accumulation of K' = 3 K per GEMM).  SURVEY 8d's gate is 1e-3 per embedding; with the ViT
 # plan (FAST_PRECISION) DATOR sits at 1.2e-3 mean / 3.0e-3 max over 448 u8 crops because the fusion head amplifies the streams' token
-# error 1.5x (3x for single crops); this plan: 3.1e-4 mean / 5.6e-4 max, at 2.1x the encoder time (44 against 21 ms per 224 crops).
+# error 1.5x (3x for single crops); this plan: 3.1e-4 mean / 5.9e-4 max, at 1.9x the encoder time (38 against 20 ms per 224 crops).
 # What is left is the fp16 rounding of q / k / v, of the softmax probabilities and of the input pixels (tools/sim_dator_rounding.py).
 DEFAULT_PRECISION = "p2;*:3333"
-FAST_PRECISION = V.DEFAULT_PRECISION          # the ViT encoders' plan: 2.1x faster, over the 1e-3 gate
+FAST_PRECISION = V.DEFAULT_PRECISION          # the ViT encoders' plan: 1.9x faster, over the 1e-3 gate
 
 HEAD_LINEARS = ["proj_local_rgb", "proj_global_rgb", "merge_rgb", "proj_local_depth", "proj_global_depth", "merge_depth",
                 "Q_r", "V_r", "Q_d", "V_d"]

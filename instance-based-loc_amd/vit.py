@@ -19,7 +19,8 @@ FLAG_FINAL_LN = 4
 FLAG_QUICK_GELU = 8
 FLAG_PROJ = 16
 FLAG_OUT_ALL_TOKENS = 32
-FLAG_ACT_TERMS = 64          # IBL_VIT_ACT_TERMS: some block takes the input of a residual GEMM in two terms (o / fc2 = 3)
+FLAG_ACT_TERMS2 = 64         # IBL_VIT_ACT_TERMS2 / 3: some block takes the input of a residual GEMM as K-extended rows of 2 / 3 terms
+FLAG_ACT_TERMS3 = 128
 MAX_LAYERS = 32
 
 
@@ -34,7 +35,8 @@ class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ls1", "ln2_g", "ln2_b",
                                           "w_fc1", "b_fc1", "w_fc2", "b_fc2", "ls2",
                                           "w_qkv_x", "w_o_lo", "ls1_lo", "w_fc1_x", "w_fc2_lo", "ls2_lo")] + \
-               [("qkv_terms", C.c_int32), ("fc1_terms", C.c_int32), ("o_terms", C.c_int32), ("fc2_terms", C.c_int32)]
+               [("qkv_terms", C.c_int32), ("fc1_terms", C.c_int32), ("o_terms", C.c_int32), ("fc2_terms", C.c_int32),
+                ("w_o_x", C.c_void_p), ("w_fc2_x", C.c_void_p)]
 
 
 class VitWeights(C.Structure):
@@ -54,6 +56,9 @@ SPLIT_SCALE = 64.0          # IBL_VIT_SPLIT_SCALE (include/ibloc.h)
 # LayerNorm output and block 2's QKV weights in two terms as well -- both ride in K-extended launches, no extra launch) 7.26e-4 / 8.59e-4,
 # 15.76 ms; "p2;0:3232;1:2222" 7.14e-4 / 8.49e-4 but 16.14 ms (the second-term launch of an fc2 costs a whole read-modify-write pass).
 DEFAULT_PRECISION = "p2;0:3232;1:2211;2:2111"
+# per-model defaults where they differ: CLIP ViT-B/32 runs 50 tokens per crop (4 ms per 224 crops), so two-term weights in every block cost
+# 2 ms and take its worst crop of 896 from 9.7e-4 -- too close to SURVEY 8d's 1e-3 gate -- to 8.1e-4 (mean 7.1e-4 -> 6.1e-4)
+MODEL_PRECISION = {"clip_b32": "p2;*:2222;0:3232"}
 
 
 def parse_precision(spec):
@@ -255,7 +260,7 @@ class VitEncoder:
         if cfg.depth > MAX_LAYERS:
             raise ValueError("too many layers")
         import os
-        self.precision = precision if precision is not None else os.environ.get("IBL_VIT_PREC", DEFAULT_PRECISION)
+        self.precision = precision if precision is not None else os.environ.get("IBL_VIT_PREC", MODEL_PRECISION.get(cfg.name, DEFAULT_PRECISION))
         patch_terms, layer_terms = parse_precision(self.precision)
         self.fold_layerscale = (os.environ.get("IBL_VIT_FOLD_LS", "0") == "1") if fold_layerscale is None else bool(fold_layerscale)
         self.cfg = cfg
@@ -317,16 +322,24 @@ class VitEncoder:
                 if tq > 1:
                     L.w_qkv_x = dev_f16(split_terms(np.concatenate([weights[p + "q.w"], weights[p + "k.w"], weights[p + "v.w"]], axis=0), tq))
                     L.qkv_terms = tq
-                L.o_terms, L.fc2_terms = to, t2
-                self._act_terms = getattr(self, "_act_terms", False) or to > 2 or t2 > 2
-                if to > 1:
+                kext = os.environ.get("IBL_VIT_RESID_KEXT", "1") != "0"       # 0: second weight terms of o / fc2 as launches of their own (rounds 3-4a)
+                self._act_terms = max(getattr(self, "_act_terms", 1), to if kext else 1, t2 if kext else 1)
+                if to > 1 and kext:
+                    L.w_o_x, L.o_terms = dev_f16(split_terms(w_o, to)), to
+                elif to > 1:
+                    if to > 2:
+                        raise ValueError("o = 3 needs the K-extended form")
                     L.w_o_lo = dev_f16(weight_lo(w_o))
                     if not fold:                             # (no vector: the library adds the term with the factor 1 / S, residual preloaded)
                         L.ls1_lo = dev_f32((weights[p + "ls1"] if cfg.layerscale else ones) / SPLIT_SCALE)
                 if t1 > 1:
                     L.w_fc1_x = dev_f16(split_terms(weights[p + "fc1.w"], t1))
                     L.fc1_terms = t1
-                if t2 > 1:
+                if t2 > 1 and kext:
+                    L.w_fc2_x, L.fc2_terms = dev_f16(split_terms(w_fc2, t2)), t2
+                elif t2 > 1:
+                    if t2 > 2:
+                        raise ValueError("fc2 = 3 needs the K-extended form")
                     L.w_fc2_lo = dev_f16(weight_lo(w_fc2))
                     if not fold:
                         L.ls2_lo = dev_f32((weights[p + "ls2"] if cfg.layerscale else ones) / SPLIT_SCALE)
@@ -337,7 +350,7 @@ class VitEncoder:
         flags |= FLAG_FINAL_LN if cfg.final_ln else 0
         flags |= FLAG_PROJ if cfg.proj_dim else 0
         flags |= FLAG_OUT_ALL_TOKENS if cfg.out_all_tokens else 0
-        flags |= FLAG_ACT_TERMS if getattr(self, "_act_terms", False) else 0
+        flags |= {1: 0, 2: FLAG_ACT_TERMS2, 3: FLAG_ACT_TERMS3}[getattr(self, "_act_terms", 1)]
         nrun = cfg.depth if cfg.n_blocks_run < 0 else cfg.n_blocks_run
         self.desc = VitDesc(cfg.dim, cfg.depth, cfg.heads, cfg.mlp_dim, cfg.patch, cfg.img_h, cfg.img_w, cfg.n_tokens,
                             cfg.patch_k_pad, flags, nrun, cfg.out_dim, cfg.ln_eps)
