@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the round-4 profile set.  usage: tools/profile_round4.sh a|b|c   (copy gpurun_out/round4/* into profiles/r04/)
+# Runs on the GPU box (via gpurun): the round-4 profile set.  usage: tools/profile_round4.sh a|b|b1|b2|c   (copy gpurun_out/round4/* into profiles/r04/)
 #   a  the driver's command (bench.py: value, value_min/max, value_with_h2d, value_adjacent, roofline, cpu_baseline), its rocprofv3 kernel
 #      summary, the last-step breakdown, the back-to-back form
 #   b  the other BASELINE configs that fit one GPU: C1, C2, C3 (DATOR), C4 slice (also through the sharded exchange at world 1)
@@ -17,10 +17,12 @@ a)
     rm -rf $OUT/prof
     timeout -k 10 300 python3 bench.py --sequential --cpu-frames 0 --ransac-budget 0 --adjacent-spacing 0 --no-h2d --repeats 1 > $OUT/bench_sequential.json
     ;;
-b)
+b|b1)
     timeout -k 10 300 python3 bench.py --config C1 > $OUT/bench_C1.json
     timeout -k 10 300 python3 bench.py --config C2 --cpu-frames 0 --ransac-budget 0 > $OUT/bench_C2.json
-    timeout -k 10 600 python3 bench.py --config C3 --ransac-budget 0 > $OUT/bench_C3_dator.json
+    timeout -k 10 500 python3 bench.py --config C3 --ransac-budget 0 > $OUT/bench_C3_dator.json
+    ;;&
+b|b2)
     timeout -k 10 300 python3 bench.py --config C4 --cpu-frames 0 > $OUT/bench_C4_m50000.json
     timeout -k 10 700 python3 bench.py --config C4 --cpu-frames 0 --layout sharded > $OUT/bench_C4_m50000_shard_rccl_world1.json
     ;;
@@ -47,5 +49,6 @@ c)
     python3 tools/pmc_round3_summary.py $OUT/pmc $OUT
     python3 tools/perf_gemm.py --stamps > $OUT/gemm_tile_stamps.txt 2>&1 || true
     ;;
-*) echo "usage: $0 a|b|c"; exit 2 ;;
+a|b1) ;;
+*) echo "usage: $0 a|b|b1|b2|c"; exit 2 ;;
 esac
