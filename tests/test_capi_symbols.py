@@ -40,3 +40,33 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         assert False, "expected IblError"
     except _lib.IblError as e:
         assert "no CPU fallback" in str(e)
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """the ctypes mirrors of the header's structs (ibloc_amd/vit.py, dator.py, preprocess.py, registration.py) have the sizes and the field
+    offsets gcc gives the declarations of include/ibloc.h -- a drifted mirror would hand the library garbage pointers"""
+    import subprocess
+    from ibloc_amd import dator as D
+    from ibloc_amd import preprocess as pp
+    from ibloc_amd import registration as R
+    from ibloc_amd import vit as V
+    pairs = [("ibl_vit_desc", V.VitDesc), ("ibl_vit_layer", V.VitLayer), ("ibl_vit_weights", V.VitWeights),
+             ("ibl_dator_head_weights", D.DatorHeadWeights), ("ibl_crop_desc", pp.CropDesc), ("ibl_instance_features", R._FeatStruct)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ibloc.h"', 'int main(void) {']
+    for cname, ct in pairs:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for (cname, ct), line in zip(pairs, out):
+        parts = line.split()
+        assert parts[0] == cname
+        assert int(parts[1]) == ctypes.sizeof(ct), f"sizeof({cname}) = {parts[1]}, ctypes mirror {ctypes.sizeof(ct)}"
+        for (fname, _), off in zip(ct._fields_, parts[2:]):
+            assert int(off) == getattr(ct, fname).offset, f"{cname}.{fname}: offset {off} in the header, {getattr(ct, fname).offset} in the mirror"
