@@ -2082,7 +2082,7 @@ struct EvalJob {
 // grid (ICP_BPJ, J): fitness / rmse partials of evaluate_registration against the whole memory
 __global__ __launch_bounds__(256) void ibl_evaluate_kernel(ibl_memgrid g, const float4* __restrict__ det, const EvalJob* __restrict__ jobs,
                                                            float thr, float thr2, double* __restrict__ partial /* [J][BPJ][2] */,
-                                                           float* __restrict__ d2_out /* per (job, point) or null */) {
+                                                           float* __restrict__ d2_out /* per (job, point) or null */, int prune) {
     const int j = blockIdx.y;
     const EvalJob job = jobs[j];
     double cnt = 0, err2 = 0;
@@ -2139,7 +2139,7 @@ __global__ __launch_bounds__(256) void ibl_evaluate_kernel(ibl_memgrid g, const 
                 for (int iz = z0; iz <= z1; ++iz) {
                     if (ix == hx && iy == hy && iz == hz) continue;
                     const float gz = face_gap(iz, hz, qz);
-                    if (gx * gx + gy * gy + gz * gz >= best) continue;
+                    if (prune && gx * gx + gy * gy + gz * gz >= best) continue;
                     scan_cell(ix, iy, iz);
                 }
             }
@@ -2191,10 +2191,12 @@ static int evaluate_impl(ibl_reg_ctx* ctx, const ibl_memgrid* grid, const float*
     IBL_ARENA(d_jobs, EvalJob, J);
     IBL_ARENA(partial, double, (int64_t)J * ICP_BPJ * 2);
     IBL_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(EvalJob) * J, hipMemcpyHostToDevice, s));
+    const char* efs = getenv("IBL_EVAL_FULLSCAN");          // diagnostics: 1 = every cell of the query's box (the tests compare both)
+    const int prune = !(efs && atoi(efs));
     void* tok;
     ibl_prof_begin(IBL_PROF_ST_EVAL, 24.0 * (double)(jobs[J - 1].out + (jobs[J - 1].end - jobs[J - 1].begin)), s, &tok);
     hipLaunchKernelGGL(ibl_evaluate_kernel, dim3(ICP_BPJ, J), dim3(256), 0, s, *grid, reinterpret_cast<const float4*>(det_pts4), d_jobs,
-                       (float)threshold, (float)(threshold * threshold), partial, d2_out);
+                       (float)threshold, (float)(threshold * threshold), partial, d2_out, prune);
     ibl_prof_end(tok, s);
     IBL_LAUNCH_CHECK();
     std::vector<double> h((size_t)J * ICP_BPJ * 2);

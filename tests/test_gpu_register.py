@@ -114,6 +114,34 @@ def test_evaluate_batch_vs_oracle(ctx, scene):
     grid.close()
 
 
+def test_evaluate_pruned_scan_equals_the_full_scan_far_from_the_origin(ctx, monkeypatch):
+    """round 4: the evaluation reads the query's own cell first and another cell of its +-threshold box only while the face it shares with
+    the own cell is nearer than the best distance so far (IBL_EVAL_FULLSCAN=1: every cell).  The bound must hold where floorf(x / cell)
+    and the geometric cell faces disagree by rounding: points 240 m from the origin, queries on cell faces, outliers, an empty job"""
+    from ibloc_amd.registration import MemGrid, evaluate_points
+    rng = np.random.default_rng(91)
+    base = np.array([241.37, -229.91, 3.03])
+    mem = (rng.uniform(-0.4, 0.4, size=(60000, 3)) * [1, 1, 0.02] + base).astype(np.float32)              # a noisy slab
+    lattice = (np.stack(np.meshgrid(np.arange(40), np.arange(40), indexing="ij"), -1).reshape(-1, 2) * 0.01 + base[:2] + 0.5).astype(np.float32)
+    mem = np.concatenate([mem, np.concatenate([lattice, np.full((len(lattice), 1), base[2], np.float32)], 1)])
+    det = np.concatenate([mem[rng.integers(0, len(mem), 20000)] + rng.normal(0, 0.004, size=(20000, 3)).astype(np.float32),
+                          (np.round(mem[rng.integers(0, len(mem), 4000)] / 0.04) * 0.04).astype(np.float32),       # on cell faces / corners
+                          (rng.uniform(-1, 1, size=(4000, 3)) + base).astype(np.float32)])                           # mostly outliers
+    mem4 = torch.from_numpy(np.concatenate([mem, np.zeros((len(mem), 1), np.float32)], 1)).cuda()
+    det4 = torch.from_numpy(np.concatenate([det, np.zeros((len(det), 1), np.float32)], 1)).cuda()
+    grid = MemGrid(ctx, mem4, 0.04)
+    T = np.stack([np.eye(4), np.eye(4), np.eye(4)])
+    T[1][:3, 3] = [0.013, -0.007, 0.004]
+    jb, je = [0, 0, 5], [len(det), len(det), 5]
+    d_p, rmse_p, fit_p = evaluate_points(ctx, grid, det4, jb, je, T, 0.02)
+    monkeypatch.setenv("IBL_EVAL_FULLSCAN", "1")
+    d_f, rmse_f, fit_f = evaluate_points(ctx, grid, det4, jb, je, T, 0.02)
+    torch.cuda.synchronize()
+    assert torch.equal(d_p, d_f) and np.array_equal(rmse_p, rmse_f) and np.array_equal(fit_p, fit_f)
+    assert 0.5 < fit_p[0] < 0.99 and fit_p[2] == 0
+    grid.close()
+
+
 @pytest.mark.parametrize("spacing", [2.5, 1.0])
 def test_register_cached_is_bit_identical(ctx, spacing):
     """instance features (per-cloud normals / FPFH / gradients reused across jobs) must not change a single bit of the
